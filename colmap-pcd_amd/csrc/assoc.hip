@@ -1,0 +1,242 @@
+// assoc.hip -- fused plane-association epilogue (double precision).
+//
+// Replaces, per 3D feature point, what the reference does right after the
+// KD-tree lookup in its three serial loops:
+//   lidar/ply.cc:95-101            winner -> Vector6d (float->double), NaN / ||n|| < 1e-6 reject
+//   lidar/lidar_point.cc:5-16,39-50 LidarPoint(l_pt, plane) -> Normalize(): n/|n|, d = 0 - a*x - b*y - c*z
+//   lidar/lidar_point.cc:21-37     ComputeDist, ComputePointToPointDist, ComputeAngle
+//   optim/bundle_adjustment.cc:381-404   classify on the raw normal, gate on max_search_range   (mode 0)
+//   sfm/incremental_mapper.cc:1444-1463  same gate, dist/angle not stored by the reference      (mode 1)
+//   controllers/bundle_adjustment.cc:156-176 gate dist2plane > 1 || dist2point > 2              (mode 2)
+// Compiled with -ffp-contract=off so the operation order below is what runs.
+#include "cloud.h"
+#include "scratch.h"
+
+namespace pcd {
+
+struct AssocOut {
+  double* lidar_xyz; double* abcd; uint8_t* type; double* dist; double* angle; double* dist2plane;
+  uint32_t* nn_idx; float* nn_sqdist;
+};
+
+__device__ __forceinline__ void assoc_core(const double X[3], const float p[3], const float nv[3], bool found,
+                                           double max_range, int mode, uint64_t i, const AssocOut& o) {
+  double l[3] = {0, 0, 0}, n[3] = {0, 0, 0}, abcd[4] = {0, 0, 0, 0};
+  double dist = 0, ang = 0, d2p = 0;
+  int type = PCD_LIDAR_NONE;
+  bool ok = found;
+  if (ok) {
+    for (int k = 0; k < 3; ++k) { l[k] = (double)p[k]; n[k] = (double)nv[k]; }
+    // ply.cc:100-101
+    bool bad = isnan(l[0]) || isnan(l[1]) || isnan(l[2]) || isnan(n[0]) || isnan(n[1]) || isnan(n[2]);
+    const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    ok = !bad && !(nn < 1e-6);
+  }
+  if (ok) {
+    // lidar_point.cc:39-50
+    double a = n[0], b = n[1], c = n[2];
+    const double norm = sqrt(a * a + b * b + c * c);
+    a = a / norm;
+    b = b / norm;
+    c = c / norm;
+    const double d = 0 - a * l[0] - b * l[1] - c * l[2];
+    abcd[0] = a; abcd[1] = b; abcd[2] = c; abcd[3] = d;
+    const double vx = X[0] - l[0], vy = X[1] - l[1], vz = X[2] - l[2];
+    const double p2p = sqrt(vx * vx + vy * vy + vz * vz);              // lidar_point.cc:27-30
+    d2p = fabs((X[0] * a + X[1] * b + X[2] * c) + d);                  // lidar_point.cc:21-25
+    const double an = fabs((a * vx + b * vy + c * vz) / p2p);          // lidar_point.cc:32-37
+    // bundle_adjustment.cc:381: raw normal, IEEE division
+    const bool ground = (fabs(n[1] / n[0]) > 10) && (fabs(n[1] / n[2]) > 10);
+    type = ground ? PCD_LIDAR_ICP_GROUND : PCD_LIDAR_ICP;
+    bool reject;
+    if (mode == PCD_GATE_CONTROLLER) reject = (d2p > 1) || (p2p > 2);
+    else reject = p2p > max_range;
+    if (reject) type = PCD_LIDAR_NONE;
+    else { dist = p2p; ang = an; }
+  }
+  if (o.lidar_xyz) { o.lidar_xyz[3 * i] = l[0]; o.lidar_xyz[3 * i + 1] = l[1]; o.lidar_xyz[3 * i + 2] = l[2]; }
+  if (o.abcd) { o.abcd[4 * i] = abcd[0]; o.abcd[4 * i + 1] = abcd[1]; o.abcd[4 * i + 2] = abcd[2]; o.abcd[4 * i + 3] = abcd[3]; }
+  if (o.type) o.type[i] = (uint8_t)type;
+  if (o.dist) o.dist[i] = dist;
+  if (o.angle) o.angle[i] = ang;
+  if (o.dist2plane) o.dist2plane[i] = d2p;
+}
+
+__global__ void k_associate(const float4* __restrict__ pts4, const float4* __restrict__ nrm4, uint64_t n,
+                            uint32_t index_base, uint32_t index_stride, const double* __restrict__ q, uint64_t Q,
+                            const uint64_t* __restrict__ keys, const double* __restrict__ max_range,
+                            uint64_t mr_count, int mode, AssocOut o) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  const uint64_t key = keys[i];
+  bool found = key != PCD_KEY_NONE;
+  float p[3] = {0, 0, 0}, nv[3] = {0, 0, 0};
+  uint32_t gi = (uint32_t)key;
+  if (found) {
+    const uint64_t li = (uint64_t)(gi - index_base) / index_stride;
+    if (li < n) {
+      const float4 a = pts4[li], b = nrm4[li];
+      p[0] = a.x; p[1] = a.y; p[2] = a.z;
+      nv[0] = b.x; nv[1] = b.y; nv[2] = b.z;
+    } else {
+      found = false;  // key of another shard: use the payload path instead
+    }
+  }
+  const double X[3] = {q[3 * i], q[3 * i + 1], q[3 * i + 2]};
+  const double mr = max_range ? max_range[mr_count == 1 ? 0 : i] : 0.0;
+  if (o.nn_idx) o.nn_idx[i] = key != PCD_KEY_NONE ? gi : 0xFFFFFFFFu;
+  if (o.nn_sqdist) o.nn_sqdist[i] = key != PCD_KEY_NONE ? __uint_as_float((uint32_t)(key >> 32)) : 3.402823466e+38f;
+  assoc_core(X, p, nv, found, mr, mode, i, o);
+}
+
+// winner (xyz, normal) of the keys this shard owns, as int32 bit patterns; zeros elsewhere
+__global__ void k_winner_payload(const float4* __restrict__ pts4, const float4* __restrict__ nrm4, uint64_t n,
+                                 uint32_t index_base, uint32_t index_stride, const uint64_t* __restrict__ keys,
+                                 uint64_t Q, int32_t* __restrict__ payload) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  const uint64_t key = keys[i];
+  int32_t out[6] = {0, 0, 0, 0, 0, 0};
+  if (key != PCD_KEY_NONE) {
+    const uint32_t gi = (uint32_t)key;
+    if (gi >= index_base && (gi - index_base) % index_stride == 0) {
+      const uint64_t li = (uint64_t)(gi - index_base) / index_stride;
+      if (li < n) {
+        const float4 a = pts4[li], b = nrm4[li];
+        out[0] = __float_as_int(a.x); out[1] = __float_as_int(a.y); out[2] = __float_as_int(a.z);
+        out[3] = __float_as_int(b.x); out[4] = __float_as_int(b.y); out[5] = __float_as_int(b.z);
+      }
+    }
+  }
+  for (int k = 0; k < 6; ++k) payload[6 * i + k] = out[k];
+}
+
+__global__ void k_associate_payload(const double* __restrict__ q, uint64_t Q, const uint64_t* __restrict__ keys,
+                                    const int32_t* __restrict__ payload, const double* __restrict__ max_range,
+                                    uint64_t mr_count, int mode, AssocOut o) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  const uint64_t key = keys[i];
+  const bool found = key != PCD_KEY_NONE;
+  float p[3], nv[3];
+  for (int k = 0; k < 3; ++k) {
+    p[k] = __int_as_float(payload[6 * i + k]);
+    nv[k] = __int_as_float(payload[6 * i + 3 + k]);
+  }
+  const double X[3] = {q[3 * i], q[3 * i + 1], q[3 * i + 2]};
+  const double mr = max_range ? max_range[mr_count == 1 ? 0 : i] : 0.0;
+  if (o.nn_idx) o.nn_idx[i] = found ? (uint32_t)key : 0xFFFFFFFFu;
+  if (o.nn_sqdist) o.nn_sqdist[i] = found ? __uint_as_float((uint32_t)(key >> 32)) : 3.402823466e+38f;
+  assoc_core(X, p, nv, found, mr, mode, i, o);
+}
+
+pcd_status nn_query_device_internal(pcd_cloud* c, const double* d_q, uint64_t Q, int algo, uint64_t* d_keys,
+                                    hipStream_t s);
+
+static AssocOut to_dev(const pcd_assoc_out* o) {
+  AssocOut a{o->lidar_xyz, o->abcd, o->type, o->dist, o->angle, o->dist2plane, o->nn_idx, o->nn_sqdist};
+  return a;
+}
+
+}  // namespace pcd
+
+using namespace pcd;
+
+extern "C" {
+
+pcd_status pcd_associate_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q, const double* d_max_range,
+                                uint64_t max_range_count, int gate_mode, const uint64_t* d_keys_in,
+                                const pcd_assoc_out* d_out, void* stream) {
+  PCD_REQUIRE(c && d_out, "null pointer");
+  PCD_REQUIRE(gate_mode >= 0 && gate_mode <= 2, "gate_mode");
+  PCD_REQUIRE(gate_mode == PCD_GATE_CONTROLLER || (d_max_range && (max_range_count == 1 || max_range_count == Q)),
+              "max_range must have 1 or Q entries");
+  if (Q == 0) return PCD_OK;
+  PCD_REQUIRE(d_q_xyz, "null queries");
+  PCD_HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t* keys = d_keys_in;
+  if (!keys) {
+    QueryScratch* sc = scratch_of(c);
+    PCD_TRY(sc->a_keys.reserve(Q));
+    PCD_TRY(nn_query_device_internal(c, d_q_xyz, Q, PCD_NN_AUTO, sc->a_keys.p, s));
+    keys = sc->a_keys.p;
+  }
+  {
+    ScopedKernelTimer t("associate", s);
+    hipLaunchKernelGGL(k_associate, dim3(div_up(Q, 256)), dim3(256), 0, s, c->pts4.p, c->nrm4.p, c->n, c->index_base,
+                       c->index_stride, d_q_xyz, Q, keys, gate_mode == PCD_GATE_CONTROLLER ? nullptr : d_max_range,
+                       max_range_count, gate_mode, to_dev(d_out));
+  }
+  PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
+
+pcd_status pcd_nn_winner_payload_device(pcd_cloud* c, const uint64_t* d_keys, uint64_t Q, int32_t* d_payload,
+                                        void* stream) {
+  PCD_REQUIRE(c && (Q == 0 || (d_keys && d_payload)), "null pointer");
+  if (Q == 0) return PCD_OK;
+  PCD_HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  ScopedKernelTimer t("winner_payload", s);
+  hipLaunchKernelGGL(k_winner_payload, dim3(div_up(Q, 256)), dim3(256), 0, s, c->pts4.p, c->nrm4.p, c->n,
+                     c->index_base, c->index_stride, d_keys, Q, d_payload);
+  PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
+
+pcd_status pcd_associate_from_payload_device(int device, const double* d_q_xyz, uint64_t Q, const double* d_max_range,
+                                             uint64_t max_range_count, int gate_mode, const uint64_t* d_keys,
+                                             const int32_t* d_payload, const pcd_assoc_out* d_out, void* stream) {
+  PCD_REQUIRE(d_out && (Q == 0 || (d_q_xyz && d_keys && d_payload)), "null pointer");
+  PCD_REQUIRE(gate_mode >= 0 && gate_mode <= 2, "gate_mode");
+  PCD_REQUIRE(gate_mode == PCD_GATE_CONTROLLER || (d_max_range && (max_range_count == 1 || max_range_count == Q)),
+              "max_range must have 1 or Q entries");
+  if (Q == 0) return PCD_OK;
+  PCD_TRY(require_device(device));
+  hipStream_t s = (hipStream_t)stream;
+  ScopedKernelTimer t("associate_payload", s);
+  hipLaunchKernelGGL(k_associate_payload, dim3(div_up(Q, 256)), dim3(256), 0, s, d_q_xyz, Q, d_keys, d_payload,
+                     gate_mode == PCD_GATE_CONTROLLER ? nullptr : d_max_range, max_range_count, gate_mode,
+                     to_dev(d_out));
+  PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
+
+pcd_status pcd_associate(pcd_cloud* c, const double* q_xyz, uint64_t Q, const double* max_range,
+                         uint64_t max_range_count, int gate_mode, const pcd_assoc_out* out) {
+  PCD_REQUIRE(c && out, "null pointer");
+  PCD_REQUIRE(gate_mode >= 0 && gate_mode <= 2, "gate_mode");
+  PCD_REQUIRE(gate_mode == PCD_GATE_CONTROLLER || (max_range && (max_range_count == 1 || max_range_count == Q)),
+              "max_range must have 1 or Q entries");
+  if (Q == 0) return PCD_OK;
+  PCD_REQUIRE(q_xyz, "null queries");
+  PCD_HIP_TRY(hipSetDevice(c->device));
+  QueryScratch& a = *scratch_of(c);
+  hipStream_t s = nullptr;
+  PCD_TRY(a.d_q.reserve(3 * Q));
+  PCD_TRY(a.a_mr.reserve(std::max<uint64_t>(max_range_count, 1)));
+  PCD_TRY(a.a_xyz.reserve(3 * Q)); PCD_TRY(a.a_abcd.reserve(4 * Q)); PCD_TRY(a.a_dist.reserve(Q));
+  PCD_TRY(a.a_angle.reserve(Q)); PCD_TRY(a.a_d2p.reserve(Q)); PCD_TRY(a.a_type.reserve(Q));
+  PCD_TRY(a.d_idx.reserve(Q)); PCD_TRY(a.d_sq.reserve(Q));
+  PCD_HIP_TRY(hipMemcpyAsync(a.d_q.p, q_xyz, 3 * Q * sizeof(double), hipMemcpyHostToDevice, s));
+  if (gate_mode != PCD_GATE_CONTROLLER)
+    PCD_HIP_TRY(hipMemcpyAsync(a.a_mr.p, max_range, max_range_count * sizeof(double), hipMemcpyHostToDevice, s));
+  pcd_assoc_out d{a.a_xyz.p, a.a_abcd.p, a.a_type.p, a.a_dist.p, a.a_angle.p, a.a_d2p.p, a.d_idx.p, a.d_sq.p};
+  PCD_TRY(pcd_associate_device(c, a.d_q.p, Q, a.a_mr.p, max_range_count, gate_mode, nullptr, &d, s));
+  auto back = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s) : hipSuccess;
+  };
+  PCD_HIP_TRY(back(out->lidar_xyz, a.a_xyz.p, 3 * Q * sizeof(double)));
+  PCD_HIP_TRY(back(out->abcd, a.a_abcd.p, 4 * Q * sizeof(double)));
+  PCD_HIP_TRY(back(out->type, a.a_type.p, Q));
+  PCD_HIP_TRY(back(out->dist, a.a_dist.p, Q * sizeof(double)));
+  PCD_HIP_TRY(back(out->angle, a.a_angle.p, Q * sizeof(double)));
+  PCD_HIP_TRY(back(out->dist2plane, a.a_d2p.p, Q * sizeof(double)));
+  PCD_HIP_TRY(back(out->nn_idx, a.d_idx.p, Q * sizeof(uint32_t)));
+  PCD_HIP_TRY(back(out->nn_sqdist, a.d_sq.p, Q * sizeof(float)));
+  PCD_HIP_TRY(hipStreamSynchronize(s));
+  return PCD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// cloud.h -- device-resident LiDAR cloud index (replaces PointCloudProcess +
+// Kdtree of the reference: lidar/ply.cc:9-57, lidar/kdtree.cc:5-8).
+//
+// HBM layout (all hipMalloc'ed on one device):
+//   pts4 [n]   float4 {x,y,z,0}     original (post-NaN-filter) row order  -- epilogue gathers, brute force
+//   nrm4 [n]   float4 {nx,ny,nz,0}  original order                        -- epilogue gathers winners only
+//   sorted [m] float4 {x,y,z,bits(global_idx)}  finite rows in cell-sorted order (x fastest):
+//              one 16-B record per lane per load; a row of cells along x is one contiguous range
+//   cell_start [ncells+1] uint32    exclusive prefix of per-cell counts
+//   blk_aabb [nblocks][8] float     tight bounds {lo.xyz, hi.xyz, 0, 0} of every 4x4x4-cell block
+#pragma once
+#include "common.h"
+
+namespace pcd {
+
+constexpr int kBlockCells = 4;  // cells per block edge (blocks carry tight AABBs for the exact fallback)
+
+struct GridParams {
+  float origin[3];
+  float h, inv_h;
+  int dims[3];    // cells
+  int bdims[3];   // blocks of kBlockCells^3 cells
+  float slack;    // metres: bound on binning rounding, see nn.hip
+};
+
+struct QueryScratch;  // nn.hip
+
+}  // namespace pcd
+
+struct pcd_cloud {
+  int device = 0;
+  uint64_t n = 0;  // rows kept
+  uint64_t m = 0;  // finite rows indexed in the grid
+  uint32_t index_base = 0, index_stride = 1;
+  pcd::DevBuf<float4> pts4, nrm4, sorted;
+  pcd::DevBuf<uint32_t> cell_start;
+  pcd::DevBuf<float> blk_aabb;
+  pcd::GridParams grid{};
+  uint64_t ncells = 0, nblocks = 0, occupied = 0;
+  double build_ms = 0;
+  pcd::QueryScratch* scratch = nullptr;
+};

@@ -1,0 +1,108 @@
+// common.h -- shared host-side plumbing of libpcdhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pcdhip.h"
+
+namespace pcd {
+
+// ----------------------------------------------------------------- errors --
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define PCD_HIP_TRY(expr)                                                              \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      ::pcd::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return (_e == hipErrorOutOfMemory) ? PCD_ERR_OOM : PCD_ERR_HIP;                  \
+    }                                                                                  \
+  } while (0)
+
+#define PCD_TRY(expr)                    \
+  do {                                   \
+    pcd_status _s = (expr);              \
+    if (_s != PCD_OK) return _s;         \
+  } while (0)
+
+#define PCD_REQUIRE(cond, msg)                                        \
+  do {                                                                \
+    if (!(cond)) {                                                    \
+      ::pcd::set_error("%s:%d: invalid argument: %s", __FILE__, __LINE__, msg); \
+      return PCD_ERR_INVALID;                                         \
+    }                                                                 \
+  } while (0)
+
+// Checks that `device` exists and is a gfx950 part.  No CPU fallback exists.
+pcd_status require_device(int device);
+
+// ------------------------------------------------------- device buffers ----
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;  // capacity in elements
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  // grow-only (keeps contents undefined)
+  pcd_status reserve(size_t count) {
+    if (count <= n) return PCD_OK;
+    release();
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), bytes);
+    if (e != hipSuccess) {
+      p = nullptr;
+      set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+      return PCD_ERR_OOM;
+    }
+    n = count;
+    return PCD_OK;
+  }
+};
+
+// --------------------------------------------------------------- profiler --
+// When enabled, every kernel launch through PCD_LAUNCH is bracketed by HIP
+// events on its own stream; bench.py reads the per-kernel totals.
+struct Profiler {
+  static Profiler& get();
+  bool enabled = false;
+  struct Rec { std::string name; hipEvent_t a, b; };
+  std::vector<Rec> pending;
+  struct Tot { std::string name; uint64_t launches; double ms; };
+  std::vector<Tot> totals;
+  std::mutex mu;
+  void begin(const char* name, hipStream_t s);
+  void end(hipStream_t s);
+  void collect();  // syncs events, folds pending into totals
+  void reset();
+};
+
+struct ScopedKernelTimer {
+  hipStream_t s;
+  bool on;
+  ScopedKernelTimer(const char* name, hipStream_t stream) : s(stream), on(Profiler::get().enabled) {
+    if (on) Profiler::get().begin(name, s);
+  }
+  ~ScopedKernelTimer() {
+    if (on) Profiler::get().end(s);
+  }
+};
+
+inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace pcd

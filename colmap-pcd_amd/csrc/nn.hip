@@ -1,0 +1,645 @@
+// nn.hip -- exact nearest neighbour of 3D feature points in the LiDAR cloud.
+//
+// Replaces lidar/kdtree.cc:10-21 (Kdtree::GetClosestPoint -> pcl::KdTreeFLANN
+// nearestKSearch, k = 1) as called from lidar/ply.cc:90-107.  Arithmetic is
+// FLANN's L2_Simple<float> on (x,y,z): ((dx*dx) + dy*dy) + dz*dz in float32
+// with separate multiplies and adds (this file is compiled with
+// -ffp-contract=off), query = (float)double (ply.cc:92).  Result = the
+// minimum of key = float_bits(d) << 32 | index over all points, i.e. ties on
+// the float distance go to the lowest index; a point only counts if
+// d < FLT_MAX (FLANN's initial worst distance).
+//
+// Three kernels, all with lanes = cloud points and wave-uniform queries, each
+// finishing with a per-wavefront min-reduction of packed keys:
+//   k_nn_bruteforce  all pairs; LDS-tiled; reference for the other two.
+//   k_nn_brick       one wavefront per group of <= G queries that fall into
+//                    the same brick of B^3 grid cells: the cell rows of the
+//                    brick grown by R cells are streamed through an LDS tile
+//                    (16-B records, coalesced row ranges) and every query of
+//                    the group is compared with every staged point.  A query
+//                    is final when its best distance is provably smaller than
+//                    its distance to the boundary of the staged region.
+//   k_nn_fallback    one wavefront per remaining query: rings of 4x4x4-cell
+//                    blocks around the query, pruned with the blocks' tight
+//                    AABBs (nearest block first), until the ring boundary is
+//                    provably farther than the best distance.  Exact for any
+//                    query position, also outside the grid.
+//
+// Exactness of the pruning (float distances, not real ones):
+//   * AABB bound: lb = l2_simple3(q, clamp(q, lo, hi)) with lo/hi the actual
+//     float min/max of the block's points.  Rounding is monotone, so for every
+//     point p of the block fl_dist(q,p) >= lb; a block is skipped only if
+//     lb > best (strictly: an equal-distance point with a lower index may hide
+//     in it).
+//   * region / ring bound: margin = min distance from q to the faces of the
+//     staged cell range (double).  A point binned outside the range can lie at
+//     most `slack` inside it because of float rounding in the binning
+//     (grid.slack = 9.6e-7 * max(extent, |coord|) >= 4 roundings of 2^-24),
+//     and its float distance is >= true^2 * (1 - 2.4e-7).  A result is final
+//     iff best < (margin - slack)^2 * (1 - 1e-6), margin > slack.
+#include <cstring>  // rocprim's texture_cache_iterator.hpp needs memset declared first
+
+#include <rocprim/rocprim.hpp>
+
+#include <cfloat>
+
+#include "cloud.h"
+#include "grid.h"
+#include "scratch.h"
+
+namespace pcd {
+
+void free_query_scratch(QueryScratch* s) { delete s; }
+
+constexpr uint64_t kKeyInit = (uint64_t)0x7F7FFFFFu << 32;  // (FLT_MAX, idx 0): nothing with d >= FLT_MAX beats it
+constexpr int kTilePts = 512;                               // LDS tile per wavefront: 512 x 16 B = 8 KiB
+constexpr int kMaxRows = 64;                                // rows of a brick region (one per lane)
+
+// ------------------------------------------------------------ brick math ---
+struct BrickParams {
+  int B, R;        // brick edge in cells, halo in cells
+  int nb[3];       // bricks per axis
+  uint32_t nbricks;
+};
+
+static BrickParams make_bricks(const GridParams& g, int B, int R) {
+  BrickParams b;
+  b.B = B; b.R = R;
+  uint64_t n = 1;
+  for (int d = 0; d < 3; ++d) { b.nb[d] = (g.dims[d] + B - 1) / B; n *= (uint64_t)b.nb[d]; }
+  b.nbricks = (uint32_t)n;
+  return b;
+}
+
+// ------------------------------------------------------- query preparation --
+// ply.cc:92: feature_point.getVector3fMap() = point_3d.cast<float>()
+__global__ void k_prepare_queries(const double* __restrict__ q, uint64_t Q, float4* __restrict__ qf4,
+                                  uint64_t* __restrict__ keys) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  float x = (float)q[3 * i], y = (float)q[3 * i + 1], z = (float)q[3 * i + 2];
+  bool ok = isfinite(x) && isfinite(y) && isfinite(z);
+  qf4[i] = make_float4(x, y, z, ok ? 1.f : 0.f);
+  keys[i] = kKeyInit;
+}
+
+// keys still at kKeyInit mean "nothing found"
+__global__ void k_finalize_keys(uint64_t* __restrict__ keys, uint64_t Q) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  if (keys[i] == kKeyInit) keys[i] = PCD_KEY_NONE;
+}
+
+__global__ void k_unpack_keys(const uint64_t* __restrict__ keys, uint64_t Q, uint32_t* __restrict__ idx,
+                              float* __restrict__ sq, uint8_t* __restrict__ found) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  uint64_t k = keys[i];
+  bool f = k != PCD_KEY_NONE;
+  idx[i] = f ? (uint32_t)k : 0xFFFFFFFFu;
+  sq[i] = f ? __uint_as_float((uint32_t)(k >> 32)) : FLT_MAX;
+  found[i] = f ? 1 : 0;
+}
+
+// ------------------------------------------------------------ brute force ---
+// thread = query, the cloud chunk of blockIdx.y is streamed through a 1024-point LDS tile
+// (broadcast reads), chunks are combined with atomicMin on the packed key.
+__global__ __launch_bounds__(256) void k_nn_bruteforce(const float4* __restrict__ pts4, uint64_t n,
+                                                        uint32_t index_base, uint32_t index_stride,
+                                                        const float4* __restrict__ qf4, uint64_t Q,
+                                                        uint64_t chunk, uint64_t* __restrict__ keys) {
+  __shared__ float4 tile[1024];
+  const uint64_t qi = blockIdx.x * (uint64_t)256 + threadIdx.x;
+  float4 q = qi < Q ? qf4[qi] : make_float4(0, 0, 0, 0);
+  uint64_t best = kKeyInit;
+  const uint64_t beg = (uint64_t)blockIdx.y * chunk;
+  const uint64_t end = beg + chunk < n ? beg + chunk : n;
+  for (uint64_t t0 = beg; t0 < end; t0 += 1024) {
+    const int tn = (int)(end - t0 < 1024 ? end - t0 : 1024);
+    __syncthreads();
+    for (int j = threadIdx.x; j < tn; j += 256) {
+      float4 p = pts4[t0 + j];
+      p.w = __uint_as_float(index_base + (uint32_t)(t0 + j) * index_stride);
+      tile[j] = p;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < tn; ++j) {
+      float4 p = tile[j];
+      float d = l2_simple3(q.x, q.y, q.z, p.x, p.y, p.z);
+      uint64_t k = make_key(d, __float_as_uint(p.w));
+      best = k < best ? k : best;
+    }
+  }
+  if (qi < Q && q.w != 0.f && best < kKeyInit) atomicMin((unsigned long long*)&keys[qi], (unsigned long long)best);
+}
+
+// ------------------------------------------------------ brick bookkeeping ---
+__global__ void k_brick_count(const float4* __restrict__ qf4, uint64_t Q, GridParams g, BrickParams b,
+                              uint32_t* __restrict__ brick_of, uint32_t* __restrict__ rank,
+                              unsigned long long* __restrict__ brick_cnt, uint32_t* __restrict__ fb_list,
+                              NnCounters* __restrict__ ctr) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  float4 q = qf4[i];
+  uint32_t bid = 0xFFFFFFFFu;
+  if (q.w != 0.f) {
+    int cx = cell_coord_raw(q.x, g.origin[0], g.inv_h, g.dims[0]);
+    int cy = cell_coord_raw(q.y, g.origin[1], g.inv_h, g.dims[1]);
+    int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
+    bool in = cx >= 0 && cx < g.dims[0] && cy >= 0 && cy < g.dims[1] && cz >= 0 && cz < g.dims[2];
+    if (in) {
+      bid = (uint32_t)(((uint64_t)(cz / b.B) * b.nb[1] + (cy / b.B)) * b.nb[0] + (cx / b.B));
+      rank[i] = (uint32_t)atomicAdd(&brick_cnt[bid], 1ull);
+    } else {
+      // outside the grid: straight to the exact fallback
+      uint32_t pos = atomicAdd(&ctr->fb_count, 1u);
+      fb_list[pos] = (uint32_t)i;
+    }
+  }
+  brick_of[i] = bid;
+}
+
+// per brick: lo32 = query count -> add item count in hi32
+template <int G>
+__global__ void k_brick_items_count(unsigned long long* __restrict__ brick_cnt, uint32_t nbricks) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbricks) return;
+  unsigned long long c = brick_cnt[b] & 0xFFFFFFFFull;
+  brick_cnt[b] = c | (((c + G - 1) / G) << 32);
+}
+
+template <int G>
+__global__ void k_brick_emit(const unsigned long long* __restrict__ brick_cnt,
+                             const unsigned long long* __restrict__ brick_off, uint32_t nbricks,
+                             uint4* __restrict__ items, NnCounters* __restrict__ ctr) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbricks) return;
+  const uint32_t cnt = (uint32_t)(brick_cnt[b] & 0xFFFFFFFFull);
+  const uint32_t qoff = (uint32_t)(brick_off[b] & 0xFFFFFFFFull), ioff = (uint32_t)(brick_off[b] >> 32);
+  const uint32_t nit = (cnt + G - 1) / G;
+  for (uint32_t k = 0; k < nit; ++k)
+    items[ioff + k] = make_uint4(qoff + k * G, b, min((uint32_t)G, cnt - k * G), 0u);
+  if (b == nbricks - 1) ctr->nitems = ioff + nit;
+}
+
+__global__ void k_brick_scatter(const uint32_t* __restrict__ brick_of, const uint32_t* __restrict__ rank,
+                                const unsigned long long* __restrict__ brick_off, uint64_t Q,
+                                uint32_t* __restrict__ q_order) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  uint32_t b = brick_of[i];
+  if (b == 0xFFFFFFFFu) return;
+  q_order[(uint32_t)(brick_off[b] & 0xFFFFFFFFull) + rank[i]] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------ brick kernel ---
+// wave-uniform copy of lane l's value (lands in an SGPR)
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t& total) {
+  const int lane = threadIdx.x & 63;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  total = __shfl(inc, 63);
+  return inc - v;
+}
+
+// squared safe radius (double) around q inside the cell range [c0,c1) per axis; faces on the
+// grid boundary do not bound anything (no points beyond them). Returns < 0 when nothing is proven.
+__device__ __forceinline__ double proven_bound(const GridParams& g, float qx, float qy, float qz, const int c0[3],
+                                               const int c1[3]) {
+  const double q[3] = {(double)qx, (double)qy, (double)qz};
+  double margin = 1e300;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (c0[d] > 0) margin = fmin(margin, q[d] - ((double)g.origin[d] + (double)c0[d] * (double)g.h));
+    if (c1[d] < g.dims[d]) margin = fmin(margin, ((double)g.origin[d] + (double)c1[d] * (double)g.h) - q[d]);
+  }
+  if (margin >= 1e300) return 1e300;  // the range covers the whole grid
+  margin -= (double)g.slack;
+  if (!(margin > 0.0)) return -1.0;
+  return margin * margin * (1.0 - 1e-6);
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_nn_brick(GridParams g, BrickParams b, const float4* __restrict__ sorted,
+                                                  const uint32_t* __restrict__ cell_start,
+                                                  const float4* __restrict__ qf4, const uint32_t* __restrict__ q_order,
+                                                  const uint4* __restrict__ items, NnCounters* __restrict__ ctr,
+                                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ fb_list,
+                                                  int collect_stats) {
+  __shared__ float4 s_tile[4][kTilePts];
+  __shared__ uint32_t s_rowoff[4][kMaxRows];
+  __shared__ uint32_t s_rowsrc[4][kMaxRows];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4* tile = s_tile[wave];
+  uint32_t* rowoff = s_rowoff[wave];
+  uint32_t* rowsrc = s_rowsrc[wave];
+  const uint32_t nitems = ctr->nitems;
+  const uint32_t nwaves = gridDim.x * 4;
+  unsigned long long st_staged = 0, st_pairs = 0, st_groups = 0;
+
+  for (uint32_t item = blockIdx.x * 4 + wave; item < nitems; item += nwaves) {
+    const uint4 it = items[item];
+    const uint32_t first = it.x, brick = it.y, cnt = it.z;
+    // --- queries of the group (wave-uniform copies) ---
+    uint32_t my_qi = 0;
+    float4 my_q = make_float4(0, 0, 0, 0);
+    if (lane < (int)cnt) {
+      my_qi = q_order[first + lane];
+      my_q = qf4[my_qi];
+    }
+    float qx[G], qy[G], qz[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      // queries beyond cnt repeat query 0: their results are never written
+      const int src = k < (int)cnt ? k : 0;
+      qx[k] = readlane_f(my_q.x, src);
+      qy[k] = readlane_f(my_q.y, src);
+      qz[k] = readlane_f(my_q.z, src);
+    }
+    // --- staged region: brick grown by R cells, clipped to the grid ---
+    const int bx = (int)(brick % b.nb[0]), by = (int)((brick / b.nb[0]) % b.nb[1]),
+              bz = (int)(brick / ((uint32_t)b.nb[0] * b.nb[1]));
+    int c0[3] = {max(bx * b.B - b.R, 0), max(by * b.B - b.R, 0), max(bz * b.B - b.R, 0)};
+    int c1[3] = {min(bx * b.B + b.B + b.R, g.dims[0]), min(by * b.B + b.B + b.R, g.dims[1]),
+                 min(bz * b.B + b.B + b.R, g.dims[2])};
+    const int ny = c1[1] - c0[1], nrows = ny * (c1[2] - c0[2]);
+    uint32_t s = 0, len = 0;
+    if (lane < nrows) {
+      const int cy = c0[1] + lane % ny, cz = c0[2] + lane / ny;
+      const uint64_t rowbase = ((uint64_t)cz * g.dims[1] + cy) * g.dims[0];
+      s = cell_start[rowbase + c0[0]];
+      len = cell_start[rowbase + c1[0]] - s;
+    }
+    uint32_t T;
+    const uint32_t off = wave_excl_scan_u32(len, T);
+    rowoff[lane] = off;
+    rowsrc[lane] = s;
+
+    uint64_t best[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) best[k] = kKeyInit;
+
+    for (uint32_t tb = 0; tb < T; tb += kTilePts) {
+      const int tn = (int)min((uint32_t)kTilePts, T - tb);
+      __builtin_amdgcn_wave_barrier();
+      // stage: flat copy of the concatenated row ranges (row of element j by binary search)
+      for (int j = lane; j < tn; j += 64) {
+        const uint32_t gi = tb + j;
+        int r = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+          if (rowoff[r + step] <= gi) r += step;   // largest r with rowoff[r] <= gi (empty rows share offsets)
+        tile[j] = sorted[rowsrc[r] + (gi - rowoff[r])];
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // compare: lanes = staged points, queries wave-uniform
+      for (int j = lane; j < tn; j += 64) {
+        const float4 p = tile[j];
+        const uint32_t pi = __float_as_uint(p.w);
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+          const float d = l2_simple3(qx[k], qy[k], qz[k], p.x, p.y, p.z);
+          const uint64_t key = make_key(d, pi);
+          best[k] = key < best[k] ? key : best[k];
+        }
+      }
+    }
+    // --- per-wavefront min reductions, one per query ---
+    uint64_t mine = kKeyInit;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const uint64_t r = wave_min_u64(best[k]);
+      if (lane == k) mine = r;
+    }
+    bool unproven = false;
+    if (lane < (int)cnt) {
+      const double bound = proven_bound(g, my_q.x, my_q.y, my_q.z, c0, c1);
+      const double bd = (double)__uint_as_float((uint32_t)(mine >> 32));
+      unproven = !(bd < bound);
+      keys[my_qi] = mine;  // final, or the starting bound of the fallback
+    }
+    const unsigned long long um = __ballot(unproven);
+    if (um) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&ctr->fb_count, (uint32_t)__popcll(um));
+      base = __shfl(base, 0);
+      if (unproven) fb_list[base + __popcll(um & ((1ull << lane) - 1))] = my_qi;
+    }
+    if (collect_stats) { st_staged += T; st_pairs += (unsigned long long)T * cnt; st_groups += 1; }
+  }
+  if (collect_stats && lane == 0) {
+    atomicAdd(&ctr->staged_points, st_staged);
+    atomicAdd(&ctr->pair_evals, st_pairs);
+    atomicAdd(&ctr->brick_groups, st_groups);
+  }
+}
+
+// --------------------------------------------------------- exact fallback ---
+// scan the point range [s,e): lanes stride over it
+__device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, uint32_t s, uint32_t e, float qx,
+                                           float qy, float qz, uint64_t& lane_best) {
+  const int lane = threadIdx.x & 63;
+  for (uint32_t i = s + lane; i < e; i += 64) {
+    const float4 p = sorted[i];
+    const float d = l2_simple3(qx, qy, qz, p.x, p.y, p.z);
+    const uint64_t key = make_key(d, __float_as_uint(p.w));
+    lane_best = key < lane_best ? key : lane_best;
+  }
+}
+
+// ring rho >= 1 around (0,0,0): t in [0, ring_cells(rho)) -> offset
+__device__ __forceinline__ void ring_offset(int rho, int t, int& dx, int& dy, int& dz) {
+  const int w = 2 * rho + 1, face = w * w;
+  if (t < 2 * face) {
+    dz = t < face ? -rho : rho;
+    const int r = t < face ? t : t - face;
+    dx = r % w - rho;
+    dy = r / w - rho;
+  } else {
+    const int u0 = t - 2 * face, per = 8 * rho;
+    dz = -rho + 1 + u0 / per;
+    const int u = u0 % per, side = u / (2 * rho), k = u % (2 * rho);
+    if (side == 0) { dx = -rho + k; dy = -rho; }
+    else if (side == 1) { dx = rho; dy = -rho + k; }
+    else if (side == 2) { dx = rho - k; dy = rho; }
+    else { dx = -rho; dy = rho - k; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, const float4* __restrict__ sorted,
+                                                      const uint32_t* __restrict__ cell_start,
+                                                      const float* __restrict__ blk_aabb,
+                                                      const float4* __restrict__ qf4,
+                                                      const uint32_t* __restrict__ list,  // NULL: queries 0..count-1
+                                                      const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
+                                                      uint64_t* __restrict__ keys, NnCounters* __restrict__ ctr,
+                                                      int collect_stats) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t count = count_ptr ? *count_ptr : count_imm;
+  const uint32_t nwaves = gridDim.x * 4;
+  unsigned long long st_pts = 0, st_q = 0;
+  for (uint32_t e = blockIdx.x * 4 + wave; e < count; e += nwaves) {
+    const uint32_t qi = list ? list[e] : e;
+    const float4 q = qf4[qi];
+    if (q.w == 0.f) continue;  // not finite: stays "not found"
+    const float qx = q.x, qy = q.y, qz = q.z;
+    uint64_t best = keys[qi];          // kKeyInit or the brick kernel's tentative result
+    uint64_t lane_best = best;
+    const int mb[3] = {cell_coord(qx, g.origin[0], g.inv_h, g.dims[0]) / kBlockCells,
+                       cell_coord(qy, g.origin[1], g.inv_h, g.dims[1]) / kBlockCells,
+                       cell_coord(qz, g.origin[2], g.inv_h, g.dims[2]) / kBlockCells};
+    const int maxrho = max(max(g.bdims[0], g.bdims[1]), g.bdims[2]);
+    for (int rho = 0; rho <= maxrho; ++rho) {
+      const int ncell = rho == 0 ? 1 : 2 * (2 * rho + 1) * (2 * rho + 1) + (2 * rho - 1) * 8 * rho;
+      for (int t0 = 0; t0 < ncell; t0 += 64) {
+        const int t = t0 + lane;
+        bool cand = false;
+        float lb = 0.f;
+        int bx = 0, by = 0, bz = 0;
+        if (t < ncell) {
+          int dx = 0, dy = 0, dz = 0;
+          if (rho) ring_offset(rho, t, dx, dy, dz);
+          bx = mb[0] + dx; by = mb[1] + dy; bz = mb[2] + dz;
+          if (bx >= 0 && bx < g.bdims[0] && by >= 0 && by < g.bdims[1] && bz >= 0 && bz < g.bdims[2]) {
+            const uint64_t blk = ((uint64_t)bz * g.bdims[1] + by) * g.bdims[0] + bx;
+            const float4 lo = *reinterpret_cast<const float4*>(blk_aabb + 8 * blk);
+            const float4 hi = *reinterpret_cast<const float4*>(blk_aabb + 8 * blk + 4);
+            // stored as {lo.x lo.y lo.z hi.x | hi.y hi.z 0 0}
+            if (lo.x <= lo.w) {  // non-empty
+              const float cx = fminf(fmaxf(qx, lo.x), lo.w), cy = fminf(fmaxf(qy, lo.y), hi.x),
+                          cz = fminf(fmaxf(qz, lo.z), hi.y);
+              lb = l2_simple3(qx, qy, qz, cx, cy, cz);
+              cand = true;
+            }
+          }
+        }
+        float best_d = __uint_as_float((uint32_t)(best >> 32));
+        cand = cand && (lb <= best_d);
+        // nearest candidate block first; re-prune the others after every block
+        while (true) {
+          const uint64_t sel = wave_min_u64(cand ? (((uint64_t)__float_as_uint(lb) << 32) | (uint32_t)lane) : ~0ull);
+          if (sel == ~0ull) break;
+          const int sl = (int)(sel & 63);
+          const int sbx = __shfl(bx, sl), sby = __shfl(by, sl), sbz = __shfl(bz, sl);
+          // the block's 16 rows (4 cells along x each): lanes 0..15 fetch the ranges
+          uint32_t rs = 0, re = 0;
+          if (lane < kBlockCells * kBlockCells) {
+            const int cy = sby * kBlockCells + (lane & 3), cz = sbz * kBlockCells + (lane >> 2);
+            if (cy < g.dims[1] && cz < g.dims[2]) {
+              const int cx0 = sbx * kBlockCells, cx1 = min(cx0 + kBlockCells, g.dims[0]);
+              const uint64_t rowbase = ((uint64_t)cz * g.dims[1] + cy) * g.dims[0];
+              rs = cell_start[rowbase + cx0];
+              re = cell_start[rowbase + cx1];
+            }
+          }
+          unsigned long long rows = __ballot(re > rs);
+          while (rows) {
+            const int r = __ffsll((long long)rows) - 1;
+            rows &= rows - 1;
+            const uint32_t a = __shfl(rs, r), bnd = __shfl(re, r);
+            scan_range(sorted, a, bnd, qx, qy, qz, lane_best);
+            st_pts += bnd - a;
+          }
+          best = wave_min_u64(lane_best);
+          best_d = __uint_as_float((uint32_t)(best >> 32));
+          if (lane == sl) cand = false;
+          cand = cand && (lb <= best_d);
+        }
+      }
+      // everything within Chebyshev block distance rho is done: provably final?
+      int c0[3], c1[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        c0[d] = max((mb[d] - rho) * kBlockCells, 0);
+        c1[d] = min((mb[d] + rho + 1) * kBlockCells, g.dims[d]);
+      }
+      const double bound = proven_bound(g, qx, qy, qz, c0, c1);
+      if ((double)__uint_as_float((uint32_t)(best >> 32)) < bound) break;
+    }
+    if (lane == 0) keys[qi] = best;
+    st_q += 1;
+  }
+  if (collect_stats && lane == 0) {
+    atomicAdd(&ctr->fallback_points, st_pts);
+    atomicAdd(&ctr->pair_evals, st_pts);
+    atomicAdd(&ctr->fallback_queries, st_q);
+  }
+}
+
+// ------------------------------------------------------------- host driver ---
+static int g_brick_B = 2, g_brick_R = 2, g_collect_stats = 0;
+
+template <int G>
+static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t* d_keys, hipStream_t s) {
+  const GridParams& g = c->grid;
+  int B = g_brick_B, R = g_brick_R;
+  if ((B + 2 * R) * (B + 2 * R) > kMaxRows) { B = 2; R = 2; }
+  const BrickParams b = make_bricks(g, B, R);
+  PCD_TRY(sc->brick_of.reserve(Q));
+  PCD_TRY(sc->rank.reserve(Q));
+  PCD_TRY(sc->q_order.reserve(Q));
+  PCD_TRY(sc->fb_list.reserve(Q));
+  PCD_TRY(sc->brick_cnt.reserve(b.nbricks));
+  PCD_TRY(sc->brick_off.reserve(b.nbricks));
+  PCD_TRY(sc->items.reserve(Q / G + std::min<uint64_t>(b.nbricks, Q) + 1));
+  PCD_TRY(sc->counters.reserve(1));
+  PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
+  PCD_HIP_TRY(hipMemsetAsync(sc->brick_cnt.p, 0, sizeof(unsigned long long) * b.nbricks, s));
+  {
+    ScopedKernelTimer t("nn_brick_bookkeeping", s);
+    hipLaunchKernelGGL(k_brick_count, dim3(div_up(Q, 256)), dim3(256), 0, s, sc->qf4.p, Q, g, b, sc->brick_of.p,
+                       sc->rank.p, sc->brick_cnt.p, sc->fb_list.p, sc->counters.p);
+    hipLaunchKernelGGL(k_brick_items_count<G>, dim3(div_up(b.nbricks, 256)), dim3(256), 0, s, sc->brick_cnt.p,
+                       b.nbricks);
+    size_t tb = 0;
+    PCD_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, sc->brick_cnt.p, sc->brick_off.p, 0ull, b.nbricks,
+                                        rocprim::plus<unsigned long long>(), s));
+    PCD_TRY(sc->tmp.reserve(tb));
+    PCD_HIP_TRY(rocprim::exclusive_scan(sc->tmp.p, tb, sc->brick_cnt.p, sc->brick_off.p, 0ull, b.nbricks,
+                                        rocprim::plus<unsigned long long>(), s));
+    hipLaunchKernelGGL(k_brick_emit<G>, dim3(div_up(b.nbricks, 256)), dim3(256), 0, s, sc->brick_cnt.p,
+                       sc->brick_off.p, b.nbricks, sc->items.p, sc->counters.p);
+    hipLaunchKernelGGL(k_brick_scatter, dim3(div_up(Q, 256)), dim3(256), 0, s, sc->brick_of.p, sc->rank.p,
+                       sc->brick_off.p, Q, sc->q_order.p);
+  }
+  {
+    ScopedKernelTimer t("nn_brick", s);
+    const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(div_up(Q, G), 4) + 1, 256 * 5);
+    hipLaunchKernelGGL(k_nn_brick<G>, dim3(blocks), dim3(256), 0, s, g, b, c->sorted.p, c->cell_start.p, sc->qf4.p,
+                       sc->q_order.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p, g_collect_stats);
+  }
+  {
+    ScopedKernelTimer t("nn_fallback", s);
+    const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), 256 * 8);
+    hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, g, c->sorted.p, c->cell_start.p,
+                       c->blk_aabb.p, sc->qf4.p, sc->fb_list.p, &sc->counters.p->fb_count, 0u, d_keys,
+                       sc->counters.p, g_collect_stats);
+  }
+  return PCD_OK;
+}
+
+static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int algo, uint64_t* d_keys,
+                            hipStream_t s) {
+  QueryScratch* sc = scratch_of(c);
+  if (Q == 0) return PCD_OK;
+  PCD_REQUIRE(Q < 0xFFFFFFF0ull, "more than 2^32 queries in one call");
+  PCD_TRY(sc->qf4.reserve(Q));
+  {
+    ScopedKernelTimer t("nn_prepare", s);
+    hipLaunchKernelGGL(k_prepare_queries, dim3(div_up(Q, 256)), dim3(256), 0, s, d_q, Q, sc->qf4.p, d_keys);
+  }
+  if (c->m > 0) {
+    if (algo == PCD_NN_BRUTEFORCE) {
+      ScopedKernelTimer t("nn_bruteforce", s);
+      // enough chunks to fill the chip even for few queries
+      const unsigned qblocks = div_up(Q, 256);
+      unsigned chunks = std::max(1u, std::min<unsigned>(div_up(c->n, 4096), 2048u / std::max(1u, qblocks)));
+      chunks = std::min(chunks, 65535u);
+      const uint64_t chunk = ((c->n + chunks - 1) / chunks + 1023) / 1024 * 1024;
+      chunks = div_up(c->n, chunk);
+      hipLaunchKernelGGL(k_nn_bruteforce, dim3(qblocks, chunks), dim3(256), 0, s, c->pts4.p, c->n, c->index_base,
+                         c->index_stride, sc->qf4.p, Q, chunk, d_keys);
+    } else if (algo == PCD_NN_FALLBACK_ONLY) {
+      PCD_TRY(sc->counters.reserve(1));
+      PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
+      ScopedKernelTimer t("nn_fallback", s);
+      const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), 256 * 8);
+      hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, c->grid, c->sorted.p, c->cell_start.p,
+                         c->blk_aabb.p, sc->qf4.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)Q,
+                         d_keys, sc->counters.p, g_collect_stats);
+    } else if (algo == PCD_NN_AUTO) {
+      PCD_TRY(run_grid<8>(c, sc, Q, d_keys, s));
+    } else {
+      set_error("unknown nn algo %d", algo);
+      return PCD_ERR_INVALID;
+    }
+  }
+  {
+    ScopedKernelTimer t("nn_finalize", s);
+    hipLaunchKernelGGL(k_finalize_keys, dim3(div_up(Q, 256)), dim3(256), 0, s, d_keys, Q);
+  }
+  PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
+
+pcd_status nn_query_device_internal(pcd_cloud* c, const double* d_q, uint64_t Q, int algo, uint64_t* d_keys,
+                                    hipStream_t s) {
+  return nn_device(c, d_q, Q, algo, d_keys, s);
+}
+
+}  // namespace pcd
+
+using namespace pcd;
+
+extern "C" {
+
+pcd_status pcd_nn_query_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q, int algo, uint64_t* d_keys,
+                               void* stream) {
+  PCD_REQUIRE(c, "null cloud");
+  PCD_REQUIRE(Q == 0 || (d_q_xyz && d_keys), "null pointer");
+  PCD_HIP_TRY(hipSetDevice(c->device));
+  return nn_device(c, d_q_xyz, Q, algo, d_keys, (hipStream_t)stream);
+}
+
+pcd_status pcd_nn_query_algo(pcd_cloud* c, const double* q_xyz, uint64_t Q, int algo, uint32_t* idx, float* sqdist,
+                             uint8_t* found) {
+  PCD_REQUIRE(c, "null cloud");
+  PCD_REQUIRE(Q == 0 || (q_xyz && idx && sqdist && found), "null pointer");
+  if (Q == 0) return PCD_OK;
+  PCD_HIP_TRY(hipSetDevice(c->device));
+  QueryScratch* sc = scratch_of(c);
+  hipStream_t s = nullptr;
+  PCD_TRY(sc->d_q.reserve(3 * Q));
+  PCD_TRY(sc->keys.reserve(Q));
+  PCD_TRY(sc->d_idx.reserve(Q));
+  PCD_TRY(sc->d_sq.reserve(Q));
+  PCD_TRY(sc->d_found.reserve(Q));
+  PCD_HIP_TRY(hipMemcpyAsync(sc->d_q.p, q_xyz, 3 * Q * sizeof(double), hipMemcpyHostToDevice, s));
+  PCD_TRY(nn_device(c, sc->d_q.p, Q, algo, sc->keys.p, s));
+  hipLaunchKernelGGL(k_unpack_keys, dim3(div_up(Q, 256)), dim3(256), 0, s, sc->keys.p, Q, sc->d_idx.p, sc->d_sq.p,
+                     sc->d_found.p);
+  PCD_HIP_TRY(hipMemcpyAsync(idx, sc->d_idx.p, Q * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  PCD_HIP_TRY(hipMemcpyAsync(sqdist, sc->d_sq.p, Q * sizeof(float), hipMemcpyDeviceToHost, s));
+  PCD_HIP_TRY(hipMemcpyAsync(found, sc->d_found.p, Q * sizeof(uint8_t), hipMemcpyDeviceToHost, s));
+  PCD_HIP_TRY(hipStreamSynchronize(s));
+  return PCD_OK;
+}
+
+pcd_status pcd_nn_query(pcd_cloud* c, const double* q_xyz, uint64_t Q, uint32_t* idx, float* sqdist, uint8_t* found) {
+  return pcd_nn_query_algo(c, q_xyz, Q, PCD_NN_AUTO, idx, sqdist, found);
+}
+
+pcd_status pcd_nn_last_stats(pcd_cloud* c, pcd_nn_stats* st) {
+  PCD_REQUIRE(c && st, "null pointer");
+  std::memset(st, 0, sizeof *st);
+  if (!c->scratch || !c->scratch->counters.p) return PCD_OK;
+  PCD_HIP_TRY(hipSetDevice(c->device));
+  PCD_HIP_TRY(hipDeviceSynchronize());
+  NnCounters h;
+  PCD_HIP_TRY(hipMemcpy(&h, c->scratch->counters.p, sizeof h, hipMemcpyDeviceToHost));
+  st->brick_groups = h.brick_groups;
+  st->staged_points = h.staged_points;
+  st->fallback_queries = h.fallback_queries;
+  st->fallback_points = h.fallback_points;
+  st->pair_evals = h.pair_evals;
+  return PCD_OK;
+}
+
+/* tuning hooks (not part of the stable ABI; used by bench.py and tests) */
+pcd_status pcd_nn_set_tuning(int brick_cells, int halo_cells, int collect_stats) {
+  if (brick_cells > 0) g_brick_B = brick_cells;
+  if (halo_cells >= 0) g_brick_R = halo_cells;
+  g_collect_stats = collect_stats;
+  return PCD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,38 @@
+// scratch.h -- grow-only per-cloud device scratch shared by nn.hip and assoc.hip
+#pragma once
+#include "cloud.h"
+
+namespace pcd {
+
+struct NnCounters {
+  unsigned long long brick_groups, staged_points, fallback_queries, fallback_points, pair_evals;
+  unsigned int nitems, fb_count;
+  unsigned int pad[2];
+};
+
+struct QueryScratch {
+  DevBuf<float4> qf4;          // (float)query, w = 1 valid / 0 not finite
+  DevBuf<uint64_t> keys;       // host-API result keys
+  DevBuf<uint32_t> brick_of;   // per query: brick id or 0xFFFFFFFF
+  DevBuf<uint32_t> rank;       // per query: rank inside its brick
+  DevBuf<uint32_t> q_order;    // brick-sorted query ids
+  DevBuf<unsigned long long> brick_cnt;  // per brick: lo32 = queries, hi32 = items (scan input)
+  DevBuf<unsigned long long> brick_off;  // exclusive scan of the above
+  DevBuf<uint4> items;         // {first, brick, count, 0}
+  DevBuf<uint32_t> fb_list;
+  DevBuf<NnCounters> counters;
+  DevBuf<char> tmp;
+  DevBuf<double> d_q;          // staging of host queries
+  DevBuf<uint32_t> d_idx; DevBuf<float> d_sq; DevBuf<uint8_t> d_found;
+  // host-API association staging
+  DevBuf<double> a_mr, a_xyz, a_abcd, a_dist, a_angle, a_d2p;
+  DevBuf<uint8_t> a_type;
+  DevBuf<uint64_t> a_keys;
+};
+
+inline QueryScratch* scratch_of(pcd_cloud* c) {
+  if (!c->scratch) c->scratch = new QueryScratch();
+  return c->scratch;
+}
+
+}  // namespace pcd

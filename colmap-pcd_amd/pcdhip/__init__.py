@@ -1,0 +1,367 @@
+"""pcdhip -- ctypes binding of libpcdhip.so (include/pcdhip.h).
+
+Plumbing only: every computation happens in the HIP library.  There is no
+CPU fallback; on a box without a gfx950 device `Cloud(...)`/`BA(...)` raise
+PcdError(PCD_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)            # colmap-pcd_amd/
+LIB_PATH = os.path.join(_ROOT, "libpcdhip.so")
+
+PCD_OK, PCD_ERR_INVALID, PCD_ERR_NO_DEVICE, PCD_ERR_HIP, PCD_ERR_OOM, PCD_ERR_UNSUPPORTED = range(6)
+NN_AUTO, NN_BRUTEFORCE, NN_FALLBACK_ONLY = 0, 1, 2
+GATE_MAPPER_LOCAL, GATE_MAPPER_GLOBAL, GATE_CONTROLLER = 0, 1, 2
+LIDAR_NONE, LIDAR_ICP, LIDAR_ICP_GROUND = 0, 1, 2
+LOSS_TRIVIAL, LOSS_SOFT_L1, LOSS_CAUCHY = 0, 1, 2
+LAYOUT_XYZ_NRM, LAYOUT_AOS32 = 0, 1
+KEY_NONE = 0x7FFFFFFFFFFFFFFF
+
+CAMERA_MODELS = ["SIMPLE_PINHOLE", "PINHOLE", "SIMPLE_RADIAL", "RADIAL", "OPENCV", "OPENCV_FISHEYE",
+                 "FULL_OPENCV", "FOV", "SIMPLE_RADIAL_FISHEYE", "RADIAL_FISHEYE", "THIN_PRISM_FISHEYE"]
+
+
+class PcdError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"pcdhip status {status}: {msg}")
+        self.status = status
+
+
+class CloudOptions(C.Structure):
+    _fields_ = [("device", C.c_int32), ("layout", C.c_int32), ("raw_lidar_frame", C.c_int32),
+                ("cell_size", C.c_float), ("index_base", C.c_uint32), ("index_stride", C.c_uint32),
+                ("reserved", C.c_int32 * 8)]
+
+
+class CloudInfo(C.Structure):
+    _fields_ = [("cell_size", C.c_float), ("origin", C.c_float * 3), ("dims", C.c_int32 * 3),
+                ("block_dims", C.c_int32 * 3), ("num_indexed", C.c_uint64), ("occupied_cells", C.c_uint64),
+                ("build_ms", C.c_double)]
+
+
+class AssocOut(C.Structure):
+    _fields_ = [("lidar_xyz", C.c_void_p), ("abcd", C.c_void_p), ("type", C.c_void_p), ("dist", C.c_void_p),
+                ("angle", C.c_void_p), ("dist2plane", C.c_void_p), ("nn_idx", C.c_void_p),
+                ("nn_sqdist", C.c_void_p)]
+
+
+class BADesc(C.Structure):
+    _fields_ = [("device", C.c_int32), ("num_cameras", C.c_int32), ("cam_model", C.c_void_p),
+                ("cam_param_offset", C.c_void_p), ("cam_params", C.c_void_p), ("cam_params_len", C.c_uint64),
+                ("num_images", C.c_int32), ("poses", C.c_void_p), ("image_camera", C.c_void_p),
+                ("image_const_pose", C.c_void_p), ("image_const_tvec", C.c_void_p),
+                ("num_points", C.c_int32), ("points", C.c_void_p), ("point_const", C.c_void_p),
+                ("num_obs", C.c_uint64), ("obs_image", C.c_void_p), ("obs_point", C.c_void_p),
+                ("obs_xy", C.c_void_p),
+                ("num_lidar", C.c_uint64), ("lidar_point", C.c_void_p), ("lidar_abcd", C.c_void_p),
+                ("lidar_weight", C.c_void_p),
+                ("loss_type", C.c_int32), ("loss_scale", C.c_double), ("camera_refine", C.c_void_p),
+                ("reserved", C.c_int32 * 8)]
+
+
+class BAOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("cost", "residuals", "jac_q", "jac_t", "jac_X", "jac_lidar",
+                                           "H_img", "g_img", "H_pt", "g_pt", "W")]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+class NNStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("queries", "brick_groups", "staged_points", "fallback_queries",
+                                           "fallback_points", "pair_evals")]
+
+
+# every symbol include/pcdhip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "pcd_last_error", "pcd_version", "pcd_device_count",
+    "pcd_cloud_options_default", "pcd_cloud_create", "pcd_cloud_destroy", "pcd_cloud_size",
+    "pcd_cloud_get_info", "pcd_cloud_download",
+    "pcd_nn_query", "pcd_nn_query_algo", "pcd_nn_query_device",
+    "pcd_associate", "pcd_associate_device", "pcd_nn_winner_payload_device",
+    "pcd_associate_from_payload_device", "pcd_search_range_schedule",
+    "pcd_camera_num_params", "pcd_ba_create", "pcd_ba_destroy", "pcd_ba_set_parameters",
+    "pcd_ba_evaluate", "pcd_ba_evaluate_device", "pcd_ba_device_parameters",
+    "pcd_profile_enable", "pcd_profile_reset", "pcd_profile_get", "pcd_nn_last_stats",
+]
+
+_LIB = None
+
+
+def build():
+    """Compile libpcdhip.so in-tree with hipcc for gfx950 (works without a GPU)."""
+    subprocess.check_call(["make", "-s", "-j4", "-C", _ROOT, "libpcdhip.so"])
+
+
+def lib():
+    """Load the HIP library.  Fails loudly if it is missing: there is no other backend."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise PcdError(PCD_ERR_NO_DEVICE, f"{LIB_PATH} not built; run __graft_entry__.build() or make -C colmap-pcd_amd")
+    L = C.CDLL(LIB_PATH)
+    L.pcd_last_error.restype = C.c_char_p
+    L.pcd_cloud_size.restype = C.c_uint64
+    L.pcd_cloud_size.argtypes = [C.c_void_p]
+    L.pcd_cloud_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(CloudOptions), C.POINTER(C.c_void_p)]
+    L.pcd_cloud_destroy.argtypes = [C.c_void_p]
+    L.pcd_cloud_destroy.restype = None
+    L.pcd_cloud_get_info.argtypes = [C.c_void_p, C.POINTER(CloudInfo)]
+    L.pcd_cloud_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pcd_nn_query_algo.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pcd_nn_query.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pcd_nn_query_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+    L.pcd_associate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
+                                C.POINTER(AssocOut)]
+    L.pcd_associate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
+                                       C.c_void_p, C.POINTER(AssocOut), C.c_void_p]
+    L.pcd_nn_winner_payload_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.pcd_associate_from_payload_device.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                    C.c_int, C.c_void_p, C.c_void_p, C.POINTER(AssocOut),
+                                                    C.c_void_p]
+    L.pcd_search_range_schedule.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    L.pcd_profile_get.argtypes = [C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
+    L.pcd_nn_last_stats.argtypes = [C.c_void_p, C.POINTER(NNStats)]
+    if hasattr(L, "pcd_ba_create"):
+        L.pcd_ba_create.argtypes = [C.POINTER(BADesc), C.POINTER(C.c_void_p)]
+        L.pcd_ba_destroy.argtypes = [C.c_void_p]
+        L.pcd_ba_destroy.restype = None
+        L.pcd_ba_set_parameters.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pcd_ba_evaluate.argtypes = [C.c_void_p, C.POINTER(BAOut)]
+        L.pcd_ba_evaluate_device.argtypes = [C.c_void_p, C.POINTER(BAOut), C.c_void_p]
+        L.pcd_ba_device_parameters.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    _LIB = L
+    return L
+
+
+def _check(st):
+    if st != PCD_OK:
+        raise PcdError(st, lib().pcd_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return lib().pcd_device_count()
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _ptr(x):
+    """numpy array -> host pointer; int -> raw (device) pointer; torch tensor -> data_ptr()."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data_as(C.c_void_p)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    return C.c_void_p(x.data_ptr())
+
+
+class Cloud:
+    """Device-resident LiDAR cloud index (reference: lidar::PointCloudProcess + lidar::Kdtree)."""
+
+    def __init__(self, xyz, nrm=None, device=0, raw_lidar_frame=True, cell_size=0.0, layout=LAYOUT_XYZ_NRM,
+                 index_base=0, index_stride=1):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        n = xyz.shape[0] if xyz.ndim > 1 else 0
+        if layout == LAYOUT_XYZ_NRM:
+            xyz = xyz.reshape(-1, 3)
+            nrm = np.ascontiguousarray(nrm, np.float32).reshape(-1, 3)
+            assert nrm.shape[0] == xyz.shape[0]
+            n = xyz.shape[0]
+        else:
+            xyz = xyz.reshape(-1, 8)
+            n = xyz.shape[0]
+        o = CloudOptions()
+        lib().pcd_cloud_options_default(C.byref(o))
+        o.device, o.layout, o.raw_lidar_frame, o.cell_size = device, layout, int(raw_lidar_frame), cell_size
+        o.index_base, o.index_stride = index_base, index_stride
+        h = C.c_void_p()
+        self._h = None
+        _check(lib().pcd_cloud_create(_vp(xyz), _vp(nrm), n, C.byref(o), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().pcd_cloud_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __len__(self):
+        return int(lib().pcd_cloud_size(self._h))
+
+    def info(self):
+        i = CloudInfo()
+        _check(lib().pcd_cloud_get_info(self._h, C.byref(i)))
+        return dict(cell_size=i.cell_size, origin=list(i.origin), dims=list(i.dims), block_dims=list(i.block_dims),
+                    num_indexed=i.num_indexed, occupied_cells=i.occupied_cells, build_ms=i.build_ms)
+
+    def download(self):
+        n = len(self)
+        xyz = np.empty((n, 3), np.float32)
+        nrm = np.empty((n, 3), np.float32)
+        _check(lib().pcd_cloud_download(self._h, _vp(xyz), _vp(nrm)))
+        return xyz, nrm
+
+    def nn(self, q, algo=NN_AUTO):
+        """Kdtree::GetClosestPoint for a batch: returns (idx uint32, sqdist float32, found uint8)."""
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        Q = q.shape[0]
+        idx = np.empty(Q, np.uint32)
+        sq = np.empty(Q, np.float32)
+        found = np.empty(Q, np.uint8)
+        _check(lib().pcd_nn_query_algo(self._h, _vp(q), Q, algo, _vp(idx), _vp(sq), _vp(found)))
+        return idx, sq, found
+
+    def nn_device(self, d_q, Q, d_keys, algo=NN_AUTO, stream=0):
+        _check(lib().pcd_nn_query_device(self._h, _ptr(d_q), Q, algo, _ptr(d_keys), C.c_void_p(stream)))
+
+    def associate(self, q, max_range=None, gate_mode=GATE_MAPPER_LOCAL):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        Q = q.shape[0]
+        out = dict(lidar_xyz=np.empty((Q, 3)), abcd=np.empty((Q, 4)), type=np.empty(Q, np.uint8),
+                   dist=np.empty(Q), angle=np.empty(Q), dist2plane=np.empty(Q),
+                   nn_idx=np.empty(Q, np.uint32), nn_sqdist=np.empty(Q, np.float32))
+        ao = AssocOut(*[_vp(out[k]) for k in ("lidar_xyz", "abcd", "type", "dist", "angle", "dist2plane",
+                                               "nn_idx", "nn_sqdist")])
+        mr, mrc = None, 0
+        if gate_mode != GATE_CONTROLLER:
+            mr = np.ascontiguousarray(np.atleast_1d(np.asarray(max_range, np.float64)))
+            mrc = mr.shape[0]
+        _check(lib().pcd_associate(self._h, _vp(q), Q, _vp(mr), mrc, gate_mode, C.byref(ao)))
+        return out
+
+    def associate_device(self, d_q, Q, d_max_range, mr_count, gate_mode, d_out, d_keys_in=None, stream=0):
+        ao = AssocOut(*[_ptr(d_out.get(k)) for k in ("lidar_xyz", "abcd", "type", "dist", "angle", "dist2plane",
+                                                      "nn_idx", "nn_sqdist")])
+        _check(lib().pcd_associate_device(self._h, _ptr(d_q), Q, _ptr(d_max_range), mr_count, gate_mode,
+                                          _ptr(d_keys_in), C.byref(ao), C.c_void_p(stream)))
+
+    def winner_payload_device(self, d_keys, Q, d_payload, stream=0):
+        _check(lib().pcd_nn_winner_payload_device(self._h, _ptr(d_keys), Q, _ptr(d_payload), C.c_void_p(stream)))
+
+    def last_stats(self):
+        s = NNStats()
+        _check(lib().pcd_nn_last_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in NNStats._fields_}
+
+
+def associate_from_payload_device(device, d_q, Q, d_max_range, mr_count, gate_mode, d_keys, d_payload, d_out,
+                                  stream=0):
+    ao = AssocOut(*[_ptr(d_out.get(k)) for k in ("lidar_xyz", "abcd", "type", "dist", "angle", "dist2plane",
+                                                  "nn_idx", "nn_sqdist")])
+    _check(lib().pcd_associate_from_payload_device(device, _ptr(d_q), Q, _ptr(d_max_range), mr_count, gate_mode,
+                                                   _ptr(d_keys), _ptr(d_payload), C.byref(ao), C.c_void_p(stream)))
+
+
+def search_range_schedule(opt_num, kd_max=1.5, kd_min=0.2, drop=0.1):
+    opt_num = np.ascontiguousarray(opt_num, np.int32)
+    out = np.empty(opt_num.shape[0], np.float64)
+    _check(lib().pcd_search_range_schedule(_vp(opt_num), opt_num.shape[0], kd_max, kd_min, drop, _vp(out)))
+    return out
+
+
+def set_nn_tuning(brick_cells=0, halo_cells=-1, collect_stats=0):
+    lib().pcd_nn_set_tuning(int(brick_cells), int(halo_cells), int(collect_stats))
+
+
+def profile_enable(on=True):
+    lib().pcd_profile_enable(int(on))
+
+
+def profile_reset():
+    lib().pcd_profile_reset()
+
+
+def profile_get():
+    arr = (KernelTime * 64)()
+    n = C.c_int(0)
+    lib().pcd_profile_get(arr, 64, C.byref(n))
+    return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n.value, 64))}
+
+
+class BA:
+    """Flat BA problem on the device (reference: what BundleAdjuster::SetUp*ByLidar builds for Ceres)."""
+
+    def __init__(self, cam_model, cam_params_list, poses, image_camera, points, obs_image, obs_point, obs_xy,
+                 lidar_point=None, lidar_abcd=None, lidar_weight=None, image_const_pose=None,
+                 image_const_tvec=None, point_const=None, loss_type=LOSS_TRIVIAL, loss_scale=1.0, device=0):
+        self.cam_model = np.ascontiguousarray(cam_model, np.int32)
+        offs, flat = [], []
+        for cp in cam_params_list:
+            offs.append(len(flat))
+            flat.extend(list(cp))
+        self.cam_param_off = np.ascontiguousarray(offs, np.int32)
+        self.cam_params = np.ascontiguousarray(flat, np.float64)
+        self.poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        self.image_camera = np.ascontiguousarray(image_camera, np.int32)
+        self.points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        self.obs_image = np.ascontiguousarray(obs_image, np.int32)
+        self.obs_point = np.ascontiguousarray(obs_point, np.int32)
+        self.obs_xy = np.ascontiguousarray(obs_xy, np.float64).reshape(-1, 2)
+        nl = 0 if lidar_point is None else len(lidar_point)
+        self.lidar_point = np.ascontiguousarray(lidar_point if nl else [], np.int32)
+        self.lidar_abcd = np.ascontiguousarray(lidar_abcd if nl else [], np.float64).reshape(-1, 4)
+        self.lidar_weight = np.ascontiguousarray(lidar_weight if nl else [], np.float64)
+        self.I, self.P, self.O, self.L = self.poses.shape[0], self.points.shape[0], len(self.obs_image), nl
+        self.image_const_pose = None if image_const_pose is None else np.ascontiguousarray(image_const_pose, np.uint8)
+        self.image_const_tvec = None if image_const_tvec is None else np.ascontiguousarray(image_const_tvec, np.uint8)
+        self.point_const = None if point_const is None else np.ascontiguousarray(point_const, np.uint8)
+        d = BADesc()
+        d.device = device
+        d.num_cameras = len(self.cam_model); d.cam_model = _vp(self.cam_model)
+        d.cam_param_offset = _vp(self.cam_param_off); d.cam_params = _vp(self.cam_params)
+        d.cam_params_len = len(self.cam_params)
+        d.num_images = self.I; d.poses = _vp(self.poses); d.image_camera = _vp(self.image_camera)
+        d.image_const_pose = _vp(self.image_const_pose); d.image_const_tvec = _vp(self.image_const_tvec)
+        d.num_points = self.P; d.points = _vp(self.points); d.point_const = _vp(self.point_const)
+        d.num_obs = self.O; d.obs_image = _vp(self.obs_image); d.obs_point = _vp(self.obs_point)
+        d.obs_xy = _vp(self.obs_xy)
+        d.num_lidar = nl; d.lidar_point = _vp(self.lidar_point); d.lidar_abcd = _vp(self.lidar_abcd)
+        d.lidar_weight = _vp(self.lidar_weight)
+        d.loss_type, d.loss_scale = int(loss_type), float(loss_scale)
+        h = C.c_void_p()
+        self._h = None
+        _check(lib().pcd_ba_create(C.byref(d), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().pcd_ba_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_parameters(self, poses=None, points=None):
+        p = None if poses is None else np.ascontiguousarray(poses, np.float64)
+        x = None if points is None else np.ascontiguousarray(points, np.float64)
+        _check(lib().pcd_ba_set_parameters(self._h, _vp(p), _vp(x)))
+
+    def evaluate(self, want=("cost", "residuals", "jac_q", "jac_t", "jac_X", "jac_lidar", "H_img", "g_img", "H_pt",
+                             "g_pt")):
+        shapes = dict(cost=(1,), residuals=(2 * self.O + self.L,), jac_q=(self.O, 2, 4), jac_t=(self.O, 2, 3),
+                      jac_X=(self.O, 2, 3), jac_lidar=(self.L, 3), H_img=(self.I, 6, 6), g_img=(self.I, 6),
+                      H_pt=(self.P, 3, 3), g_pt=(self.P, 3), W=(self.O, 6, 3))
+        out = {k: np.zeros(shapes[k]) for k in want}
+        bo = BAOut(*[_vp(out.get(n)) for n, _ in BAOut._fields_])
+        _check(lib().pcd_ba_evaluate(self._h, C.byref(bo)))
+        return out
+
+    def evaluate_device(self, d_out, stream=0):
+        bo = BAOut(*[_ptr(d_out.get(n)) for n, _ in BAOut._fields_])
+        _check(lib().pcd_ba_evaluate_device(self._h, C.byref(bo), C.c_void_p(stream)))
+
+    def device_parameters(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(lib().pcd_ba_device_parameters(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,304 @@
+/*
+ * pcdhip.h -- C ABI of libpcdhip.so, the MI355X (gfx950) implementation of
+ * colmap-pcd's image-to-LiDAR registration hot path.
+ *
+ * The reference (Wangshihu12/colmap-pcd) has no plugin/FFI API for this
+ * path: it is reached through C++ call sites.  Every entry point below names
+ * the reference interface it replaces (paths relative to the reference's
+ * src/).  C++ adapters with the reference's own signatures live in
+ * colmap-pcd_amd/shim/; INTEGRATION.md shows the call-site patch.
+ *
+ * Conventions
+ *   - every function returns a pcd_status (0 = OK) and never throws;
+ *   - host pointers unless the name ends in _device; the caller owns all
+ *     buffers it passes, the library owns device memory behind the handles;
+ *   - a handle is bound to one HIP device and may be used from one thread at
+ *     a time; different handles are independent;
+ *   - `stream` arguments are hipStream_t passed as void* (NULL = default
+ *     stream); _device calls are asynchronous on that stream;
+ *   - there is NO CPU fallback: without a usable gfx950 device every entry
+ *     point that computes returns PCD_ERR_NO_DEVICE.
+ */
+#ifndef PCDHIP_H_
+#define PCDHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCDHIP_VERSION_MAJOR 0
+#define PCDHIP_VERSION_MINOR 1
+
+typedef enum {
+  PCD_OK = 0,
+  PCD_ERR_INVALID = 1,     /* bad argument (null pointer, size mismatch, unknown enum) */
+  PCD_ERR_NO_DEVICE = 2,   /* no HIP device / wrong architecture                       */
+  PCD_ERR_HIP = 3,         /* a HIP runtime call failed; see pcd_last_error()          */
+  PCD_ERR_OOM = 4,
+  PCD_ERR_UNSUPPORTED = 5
+} pcd_status;
+
+const char* pcd_last_error(void);            /* thread-local message of the last failure */
+int pcd_version(void);                       /* major*100 + minor                         */
+int pcd_device_count(void);                  /* number of usable gfx950 devices (0 on a CPU box) */
+
+/* ------------------------------------------------------------------------
+ * LiDAR cloud index                         replaces lidar/ply.cc:9-57
+ *   PointCloudProcess::Initialize -> PointCloudDirectionTrans -> Kdtree::BuildMap
+ *   (lidar/kdtree.cc:5-8, pcl::KdTreeFLANN::setInputCloud)
+ * --------------------------------------------------------------------- */
+typedef struct pcd_cloud pcd_cloud;
+
+typedef enum {
+  PCD_LAYOUT_XYZ_NRM = 0,  /* xyz[n][3] floats + nrm[n][3] floats (two arrays)             */
+  PCD_LAYOUT_AOS32 = 1     /* lidarpt::Point, lidar/pt_type.h:14-30: x y z pad nx ny nz pad */
+} pcd_layout;
+
+typedef struct {
+  int32_t device;           /* HIP device ordinal                                           */
+  int32_t layout;           /* pcd_layout                                                   */
+  int32_t raw_lidar_frame;  /* 1: input rows are in the PLY/LiDAR frame: apply ply.cc:38-54 */
+                            /*    (x,y,z)->(-y,-z,x) to position and normal and drop rows   */
+                            /*    with a NaN; 0: rows are already transformed and filtered  */
+  float cell_size;          /* grid cell edge in metres, 0 = choose from point density      */
+  uint32_t index_base;      /* global index of local row i = index_base + i*index_stride:   */
+  uint32_t index_stride;    /*    lets N ranks each hold every N-th row of one cloud        */
+                            /*    (0 is read as 1).  Requires raw_lidar_frame == 0 if != 1. */
+  int32_t reserved[8];
+} pcd_cloud_options;
+
+void pcd_cloud_options_default(pcd_cloud_options* o);
+
+/* xyz: n rows (layout XYZ_NRM: 3 floats/row; AOS32: 8 floats/row, nrm ignored). */
+pcd_status pcd_cloud_create(const float* xyz, const float* nrm, uint64_t n,
+                            const pcd_cloud_options* opts, pcd_cloud** out);
+void pcd_cloud_destroy(pcd_cloud* c);
+
+/* rows kept after the NaN filter (index space of every idx returned below) */
+uint64_t pcd_cloud_size(const pcd_cloud* c);
+
+typedef struct {
+  float cell_size;
+  float origin[3];
+  int32_t dims[3];           /* fine grid cells per axis                                     */
+  int32_t block_dims[3];     /* 4x4x4-cell blocks per axis                                   */
+  uint64_t num_indexed;      /* finite points in the grid (Inf rows keep an index, never win) */
+  uint64_t occupied_cells;
+  double build_ms;
+} pcd_cloud_info;
+pcd_status pcd_cloud_get_info(const pcd_cloud* c, pcd_cloud_info* info);
+
+/* copy the transformed / filtered cloud back (tests; GUI display path ply.cc:59-84 wants it) */
+pcd_status pcd_cloud_download(const pcd_cloud* c, float* xyz /*[size][3]*/, float* nrm /*[size][3]*/);
+
+/* ------------------------------------------------------------------------
+ * Nearest neighbour                          replaces lidar/kdtree.cc:10-21
+ *   Kdtree::GetClosestPoint  (k = 1 pcl::KdTreeFLANN::nearestKSearch,
+ *   FLANN L2_Simple<float> on x,y,z; exact)
+ * query = (float)q_xyz (lidar/ply.cc:92).  Ties on the float distance go to
+ * the lowest index.  found = 0: empty cloud, non-finite query, or nothing
+ * closer than FLT_MAX; idx is then 0xFFFFFFFF and sqdist FLT_MAX.
+ * --------------------------------------------------------------------- */
+typedef enum {
+  PCD_NN_AUTO = 0,        /* grid kernels (brick LDS tiles + exact fallback)  */
+  PCD_NN_BRUTEFORCE = 1,  /* tiled all-pairs kernel: reference for the others */
+  PCD_NN_FALLBACK_ONLY = 2/* per-wavefront hierarchical search for every query */
+} pcd_nn_algo;
+
+pcd_status pcd_nn_query(pcd_cloud* c, const double* q_xyz /*[Q][3]*/, uint64_t Q,
+                        uint32_t* idx, float* sqdist, uint8_t* found);
+pcd_status pcd_nn_query_algo(pcd_cloud* c, const double* q_xyz, uint64_t Q, int algo,
+                             uint32_t* idx, float* sqdist, uint8_t* found);
+
+/* Device-resident form.  keys[i] = (uint64)float_bits(sqdist) << 32 | global_idx,
+ * PCD_KEY_NONE when nothing was found.  sqdist is a non-negative float, so the
+ * unsigned AND the signed 64-bit order of keys equal the (distance, index)
+ * order, and PCD_KEY_NONE is the largest value in both: shards of one cloud
+ * combine with an element-wise MIN (RCCL ncclMin on ncclUint64 or ncclInt64). */
+#define PCD_KEY_NONE 0x7FFFFFFFFFFFFFFFull
+pcd_status pcd_nn_query_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q, int algo,
+                               uint64_t* d_keys, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Plane association                          replaces the three serial loops
+ *   optim/bundle_adjustment.cc:358-410  BundleAdjustmentConfig::MatchClosestLidarPoint   (PCD_GATE_MAPPER_LOCAL)
+ *   sfm/incremental_mapper.cc:1413-1469 IncrementalMapper::AdjustGlobalBundleByLidar     (PCD_GATE_MAPPER_GLOBAL)
+ *   controllers/bundle_adjustment.cc:130-185 BundleAdjustmentController::Run             (PCD_GATE_CONTROLLER)
+ * each of which does: lidar/ply.cc:90-107 SearchNearestNeiborByKdtree ->
+ * lidar/lidar_point.cc:5-50 LidarPoint(l_pt, plane) / Normalize ->
+ * classification on the raw normal -> range gate.
+ * --------------------------------------------------------------------- */
+typedef enum { PCD_GATE_MAPPER_LOCAL = 0, PCD_GATE_MAPPER_GLOBAL = 1, PCD_GATE_CONTROLLER = 2 } pcd_gate_mode;
+typedef enum { PCD_LIDAR_NONE = 0, PCD_LIDAR_ICP = 1, PCD_LIDAR_ICP_GROUND = 2 } pcd_lidar_type;
+
+typedef struct {
+  double* lidar_xyz;   /* [Q][3] LidarPoint::LidarXYZ()  (winner position as doubles)        */
+  double* abcd;        /* [Q][4] LidarPoint::LidarABCD() after Normalize()                   */
+  uint8_t* type;       /* [Q]    pcd_lidar_type; 0 = the reference records no LidarPoint     */
+  double* dist;        /* [Q]    point-to-point distance (SetDist at bundle_adjustment.cc:403) */
+  double* angle;       /* [Q]    ComputeAngle (SetAngle at :404)                              */
+  double* dist2plane;  /* [Q]    ComputeDist, may be NULL                                     */
+  uint32_t* nn_idx;    /* [Q]    winner index, may be NULL                                    */
+  float* nn_sqdist;    /* [Q]    may be NULL                                                  */
+} pcd_assoc_out;
+
+/* max_range: Q entries (per-point schedule, sfm/incremental_mapper.cc:1159-1163) or
+ * one entry broadcast when max_range_count == 1; ignored for PCD_GATE_CONTROLLER. */
+pcd_status pcd_associate(pcd_cloud* c, const double* q_xyz, uint64_t Q, const double* max_range,
+                         uint64_t max_range_count, int gate_mode, const pcd_assoc_out* out);
+
+/* Device form: every pointer in `out` and d_q_xyz / d_max_range are device
+ * pointers.  d_keys_in == NULL: run the search; otherwise use these keys
+ * (e.g. after a cross-rank MIN) and skip the search. */
+pcd_status pcd_associate_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q, const double* d_max_range,
+                                uint64_t max_range_count, int gate_mode, const uint64_t* d_keys_in,
+                                const pcd_assoc_out* d_out, void* stream);
+
+/* Sharded clouds: after the MIN over ranks each rank fills winner (xyz, normal)
+ * for the keys it owns and zeros elsewhere: d_payload [Q][6] floats as int32 bit
+ * patterns, so that a SUM over ranks reassembles them bit-exactly.
+ * pcd_associate_from_payload_device then runs the epilogue on any rank. */
+pcd_status pcd_nn_winner_payload_device(pcd_cloud* c, const uint64_t* d_keys, uint64_t Q,
+                                        int32_t* d_payload, void* stream);
+pcd_status pcd_associate_from_payload_device(int device, const double* d_q_xyz, uint64_t Q,
+                                             const double* d_max_range, uint64_t max_range_count,
+                                             int gate_mode, const uint64_t* d_keys, const int32_t* d_payload,
+                                             const pcd_assoc_out* d_out, void* stream);
+
+/* search-radius schedule, sfm/incremental_mapper.cc:1159-1163, 1423-1427 */
+pcd_status pcd_search_range_schedule(const int32_t* global_opt_num, uint64_t n, double kd_max,
+                                     double kd_min, double drop_speed, double* out);
+
+/* ------------------------------------------------------------------------
+ * Bundle-adjustment residual / Jacobian evaluation
+ *   replaces what ceres::Solve calls per iteration on the problem built by
+ *   optim/bundle_adjustment.cc:694-1131: for every residual block
+ *   ceres::CostFunction::Evaluate(parameters, residuals, jacobians) of
+ *     base/cost_functions.h:49-141   BundleAdjustmentCostFunction<Model>            (variable pose)
+ *     base/cost_functions.h:256-370  BundleAdjustmentConstantPoseCostFunction<Model>
+ *     base/cost_functions.h:150-241  BundleAdjustmentLidarCostFunction
+ *   with base/camera_models.h WorldToImage of the 11 models, followed by the
+ *   loss correction (optim/bundle_adjustment.cc:53-68) and the quaternion /
+ *   subset manifolds (base/cost_functions.h:610-627).
+ * --------------------------------------------------------------------- */
+typedef struct pcd_ba pcd_ba;
+
+typedef enum { PCD_LOSS_TRIVIAL = 0, PCD_LOSS_SOFT_L1 = 1, PCD_LOSS_CAUCHY = 2 } pcd_loss_type;
+
+/* model ids = CameraModel::kModelId, base/camera_models.h:187-347 */
+typedef enum {
+  PCD_CAM_SIMPLE_PINHOLE = 0, PCD_CAM_PINHOLE = 1, PCD_CAM_SIMPLE_RADIAL = 2, PCD_CAM_RADIAL = 3,
+  PCD_CAM_OPENCV = 4, PCD_CAM_OPENCV_FISHEYE = 5, PCD_CAM_FULL_OPENCV = 6, PCD_CAM_FOV = 7,
+  PCD_CAM_SIMPLE_RADIAL_FISHEYE = 8, PCD_CAM_RADIAL_FISHEYE = 9, PCD_CAM_THIN_PRISM_FISHEYE = 10
+} pcd_camera_model;
+int pcd_camera_num_params(int model_id);   /* -1 for an unknown id */
+
+/* Flat problem description (all host pointers, copied at create).
+ * It is what BundleAdjuster::SetUp*ByLidar assembles block by block:
+ *   cameras  <- Camera::ParamsData()            optim/bundle_adjustment.cc:828
+ *   images   <- Image::Qvec()/Tvec()            :825-826   (qw qx qy qz tx ty tz)
+ *   points   <- Point3D::XYZ()                  :894
+ *   obs      <- one per AddResidualBlock of a reprojection functor :875,:893,:982
+ *   lidar    <- one per AddLidarToProblem       :993-1040 (abcd NaN rows must be dropped by the caller
+ *               exactly as :1005-1009 does; weight chosen by type :1013-1028)
+ * image_const_pose[i] = !refine_extrinsics || HasConstantPose(i) (:831) or the
+ * image is outside the config (:967-983): such blocks use the constant-pose functor.
+ * image_const_tvec[i] bit k = tvec[k] held constant (SetSubsetManifold :912-915).
+ * point_const[p] = ParameterizePoints (:1107-1131).
+ * Intrinsics are held constant (ba_refine_* default false,
+ * controllers/incremental_mapper.h:156-158) unless camera_refine != NULL
+ * (not implemented in this version: PCD_ERR_UNSUPPORTED). */
+typedef struct {
+  int32_t device;
+  int32_t num_cameras;
+  const int32_t* cam_model;        /* [C]                        */
+  const int32_t* cam_param_offset; /* [C] start in cam_params    */
+  const double* cam_params;        /* packed                     */
+  uint64_t cam_params_len;
+  int32_t num_images;
+  const double* poses;             /* [I][7]                     */
+  const int32_t* image_camera;     /* [I]                        */
+  const uint8_t* image_const_pose; /* [I] or NULL (all variable) */
+  const uint8_t* image_const_tvec; /* [I] or NULL                */
+  int32_t num_points;
+  const double* points;            /* [P][3]                     */
+  const uint8_t* point_const;      /* [P] or NULL                */
+  uint64_t num_obs;
+  const int32_t* obs_image;        /* [O]                        */
+  const int32_t* obs_point;        /* [O]                        */
+  const double* obs_xy;            /* [O][2]                     */
+  uint64_t num_lidar;
+  const int32_t* lidar_point;      /* [L]                        */
+  const double* lidar_abcd;        /* [L][4]                     */
+  const double* lidar_weight;      /* [L]                        */
+  int32_t loss_type;               /* pcd_loss_type              */
+  double loss_scale;
+  const uint8_t* camera_refine;    /* must be NULL               */
+  int32_t reserved[8];
+} pcd_ba_desc;
+
+pcd_status pcd_ba_create(const pcd_ba_desc* desc, pcd_ba** out);
+void pcd_ba_destroy(pcd_ba* ba);
+
+/* parameter update between iterations (host -> device); NULL keeps the old values */
+pcd_status pcd_ba_set_parameters(pcd_ba* ba, const double* poses /*[I][7]*/, const double* points /*[P][3]*/);
+
+/* Outputs of one evaluation; every pointer may be NULL (not computed / not copied).
+ * Raw blocks are exactly what each CostFunction::Evaluate hands to Ceres
+ * (row-major num_residuals x block_size, ambient quaternion size 4):
+ *   residuals [2*O + L]   obs blocks first, then lidar blocks
+ *   jac_q [O][2][4]  jac_t [O][2][3]  jac_X [O][2][3]   (zero rows for constant-pose blocks)
+ *   jac_lidar [L][3]
+ * Normal-equation blocks use the loss-corrected residuals/Jacobians projected on
+ * the manifolds (pose tangent = 3 quaternion-tangent + 3 tvec):
+ *   H_img [I][6][6] g_img [I][6]   H_pt [P][3][3] g_pt [P][3]   W [O][6][3] = Jp^T JX */
+typedef struct {
+  double* cost;        /* [1]  1/2 sum rho(||r_block||^2) */
+  double* residuals;
+  double* jac_q;
+  double* jac_t;
+  double* jac_X;
+  double* jac_lidar;
+  double* H_img;
+  double* g_img;
+  double* H_pt;
+  double* g_pt;
+  double* W;
+} pcd_ba_out;
+
+pcd_status pcd_ba_evaluate(pcd_ba* ba, const pcd_ba_out* out);                 /* host outputs   */
+pcd_status pcd_ba_evaluate_device(pcd_ba* ba, const pcd_ba_out* d_out, void* stream);  /* device outputs */
+/* device-side parameter pointers for zero-copy updates: [I][7] and [P][3] doubles */
+pcd_status pcd_ba_device_parameters(pcd_ba* ba, double** d_poses, double** d_points);
+
+/* ------------------------------------------------------------------------
+ * Profiling hooks used by bench.py (HIP events on the launch stream)
+ * --------------------------------------------------------------------- */
+typedef struct {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+} pcd_kernel_time;
+pcd_status pcd_profile_enable(int on);
+pcd_status pcd_profile_reset(void);
+/* fills up to cap entries, returns the number of distinct kernels in *count (syncs the device) */
+pcd_status pcd_profile_get(pcd_kernel_time* entries, int cap, int* count);
+
+/* statistics of the last pcd_nn_query*(…, PCD_NN_AUTO) call on this handle */
+typedef struct {
+  uint64_t queries;
+  uint64_t brick_groups;        /* wavefront work items of the brick kernel                 */
+  uint64_t staged_points;       /* sum over groups of points staged through LDS             */
+  uint64_t fallback_queries;    /* queries finished by the exact hierarchical kernel        */
+  uint64_t fallback_points;     /* points scanned by that kernel                            */
+  uint64_t pair_evals;          /* distance evaluations, both kernels                       */
+} pcd_nn_stats;
+pcd_status pcd_nn_last_stats(pcd_cloud* c, pcd_nn_stats* s);   /* syncs */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCDHIP_H_ */

@@ -1,0 +1,259 @@
+"""ctypes loader for oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module.  The product path (colmap-pcd_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build():
+    """Compile the oracle with gcc/g++ (no GPU, no reference sources needed)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+class BAProblem(C.Structure):
+    _fields_ = [
+        ("num_cameras", C.c_int32), ("cam_model", C.c_void_p), ("cam_param_off", C.c_void_p),
+        ("cam_params", C.c_void_p),
+        ("num_images", C.c_int32), ("poses", C.c_void_p), ("image_camera", C.c_void_p),
+        ("image_const_pose", C.c_void_p), ("image_const_tvec", C.c_void_p),
+        ("num_points", C.c_int32), ("points", C.c_void_p), ("point_const", C.c_void_p),
+        ("num_obs", C.c_int64), ("obs_image", C.c_void_p), ("obs_point", C.c_void_p), ("obs_xy", C.c_void_p),
+        ("num_lidar", C.c_int64), ("lidar_point", C.c_void_p), ("lidar_abcd", C.c_void_p),
+        ("lidar_weight", C.c_void_p),
+        ("loss_type", C.c_int32), ("loss_scale", C.c_double), ("cam_jac_stride", C.c_int32),
+    ]
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    L.oracle_direction_trans.restype = C.c_uint64
+    L.oracle_direction_trans.argtypes = [f32p, f32p, C.c_uint64, f32p, f32p]
+    L.oracle_nn_bruteforce.restype = None
+    L.oracle_nn_bruteforce.argtypes = [f32p, C.c_uint64, f64p, C.c_uint64, u32p, f32p, u8p]
+    L.oracle_kdtree_build.restype = C.c_void_p
+    L.oracle_kdtree_build.argtypes = [f32p, C.c_uint64, C.c_int]
+    L.oracle_kdtree_free.restype = None
+    L.oracle_kdtree_free.argtypes = [C.c_void_p]
+    L.oracle_kdtree_query.restype = None
+    L.oracle_kdtree_query.argtypes = [C.c_void_p, f64p, C.c_uint64, u32p, f32p, u8p]
+    L.oracle_search_nearest_neibor.restype = None
+    L.oracle_search_nearest_neibor.argtypes = [f32p, f32p, u32p, u8p, C.c_uint64, f64p, u8p]
+    L.oracle_associate.restype = None
+    L.oracle_associate.argtypes = [f64p, f64p, u8p, C.c_void_p, C.c_uint64, C.c_int, f64p, u8p, f64p, f64p, f64p]
+    L.oracle_search_range_schedule.restype = None
+    L.oracle_search_range_schedule.argtypes = [i32p, C.c_uint64, C.c_double, C.c_double, C.c_double, f64p]
+    L.oracle_camera_num_params.restype = C.c_int
+    L.oracle_camera_num_params.argtypes = [C.c_int]
+    L.oracle_reproj_residual.restype = None
+    L.oracle_reproj_residual.argtypes = [C.c_int, f64p, f64p, f64p, f64p, f64p, f64p]
+    L.oracle_reproj_block.restype = None
+    L.oracle_reproj_block.argtypes = [C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p]
+    L.oracle_lidar_block.restype = None
+    L.oracle_lidar_block.argtypes = [f64p, f64p, C.c_double, C.c_int, f64p, f64p]
+    L.oracle_loss.restype = None
+    L.oracle_loss.argtypes = [C.c_int, C.c_double, C.c_double, f64p]
+    L.oracle_ba_evaluate_raw.restype = None
+    L.oracle_ba_evaluate_raw.argtypes = [C.POINTER(BAProblem)] + [C.c_void_p] * 6
+    L.oracle_ba_normal_equations.restype = C.c_double
+    L.oracle_ba_normal_equations.argtypes = [C.POINTER(BAProblem)] + [C.c_void_p] * 5
+    _LIB = L
+    return L
+
+
+# ------------------------------------------------------------------ NN ----
+def direction_trans(xyz_raw, nrm_raw):
+    xyz_raw = np.ascontiguousarray(xyz_raw, np.float32)
+    nrm_raw = np.ascontiguousarray(nrm_raw, np.float32)
+    n = xyz_raw.shape[0]
+    xo = np.empty((n, 3), np.float32)
+    no = np.empty((n, 3), np.float32)
+    m = lib().oracle_direction_trans(xyz_raw, nrm_raw, n, xo, no)
+    return xo[:m].copy(), no[:m].copy()
+
+
+def nn_bruteforce(xyz, q):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+    nq = q.shape[0]
+    idx = np.empty(nq, np.uint32)
+    sq = np.empty(nq, np.float32)
+    found = np.empty(nq, np.uint8)
+    lib().oracle_nn_bruteforce(xyz, xyz.shape[0], q, nq, idx, sq, found)
+    return idx, sq, found
+
+
+class KDTree:
+    def __init__(self, xyz, leaf_max=15):
+        self._xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        self._h = lib().oracle_kdtree_build(self._xyz, self._xyz.shape[0], leaf_max)
+
+    def query(self, q):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        nq = q.shape[0]
+        idx = np.empty(nq, np.uint32)
+        sq = np.empty(nq, np.float32)
+        found = np.empty(nq, np.uint8)
+        lib().oracle_kdtree_query(self._h, q, nq, idx, sq, found)
+        return idx, sq, found
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_kdtree_free(self._h)
+            self._h = None
+
+
+def search_nearest_neibor(xyz, nrm, idx, found):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    nrm = np.ascontiguousarray(nrm, np.float32).reshape(-1, 3)
+    nq = idx.shape[0]
+    out6 = np.empty((nq, 6), np.float64)
+    ok = np.empty(nq, np.uint8)
+    lib().oracle_search_nearest_neibor(xyz, nrm, np.ascontiguousarray(idx, np.uint32),
+                                       np.ascontiguousarray(found, np.uint8), nq, out6, ok)
+    return out6, ok
+
+
+GATE_MAPPER_LOCAL, GATE_MAPPER_GLOBAL, GATE_CONTROLLER = 0, 1, 2
+
+
+def associate(X, out6, ok, max_range, gate_mode):
+    X = np.ascontiguousarray(X, np.float64).reshape(-1, 3)
+    nq = X.shape[0]
+    out6 = np.ascontiguousarray(out6, np.float64)
+    ok = np.ascontiguousarray(ok, np.uint8)
+    abcd = np.empty((nq, 4), np.float64)
+    typ = np.empty(nq, np.uint8)
+    dist = np.empty(nq, np.float64)
+    ang = np.empty(nq, np.float64)
+    d2p = np.empty(nq, np.float64)
+    mr = None
+    if max_range is not None:
+        mr_arr = np.ascontiguousarray(np.broadcast_to(np.asarray(max_range, np.float64), (nq,)))
+        mr = mr_arr.ctypes.data_as(C.c_void_p)
+    lib().oracle_associate(X, out6, ok, mr, nq, gate_mode, abcd, typ, dist, ang, d2p)
+    return abcd, typ, dist, ang, d2p
+
+
+def search_range_schedule(opt_num, kd_max=1.5, kd_min=0.2, drop=0.1):
+    opt_num = np.ascontiguousarray(opt_num, np.int32)
+    out = np.empty(opt_num.shape[0], np.float64)
+    lib().oracle_search_range_schedule(opt_num, opt_num.shape[0], kd_max, kd_min, drop, out)
+    return out
+
+
+# ------------------------------------------------------------------ BA ----
+CAMERA_MODELS = ["SIMPLE_PINHOLE", "PINHOLE", "SIMPLE_RADIAL", "RADIAL", "OPENCV", "OPENCV_FISHEYE",
+                 "FULL_OPENCV", "FOV", "SIMPLE_RADIAL_FISHEYE", "RADIAL_FISHEYE", "THIN_PRISM_FISHEYE"]
+NUM_PARAMS = [3, 4, 4, 5, 8, 8, 12, 5, 4, 5, 12]
+
+
+def reproj_residual(model, q, t, X, cam, obs):
+    r = np.empty(2, np.float64)
+    a = [np.ascontiguousarray(v, np.float64) for v in (q, t, X, cam, obs)]
+    lib().oracle_reproj_residual(model, *a, r)
+    return r
+
+
+def reproj_block(model, q, t, X, cam, obs):
+    K = NUM_PARAMS[model]
+    r = np.empty(2, np.float64)
+    Jq = np.empty((2, 4)); Jt = np.empty((2, 3)); JX = np.empty((2, 3)); Jc = np.empty((2, K))
+    a = [np.ascontiguousarray(v, np.float64) for v in (q, t, X, cam, obs)]
+    lib().oracle_reproj_block(model, *a, r, Jq, Jt, JX, Jc)
+    return r, Jq, Jt, JX, Jc
+
+
+def lidar_block(X, abcd, w, strict=False):
+    r = np.empty(1, np.float64)
+    J = np.empty(3, np.float64)
+    lib().oracle_lidar_block(np.ascontiguousarray(X, np.float64), np.ascontiguousarray(abcd, np.float64),
+                             float(w), int(strict), r, J)
+    return r[0], J
+
+
+def loss(type_, scale, s):
+    rho = np.empty(3, np.float64)
+    lib().oracle_loss(type_, scale, s, rho)
+    return rho
+
+
+class BA:
+    """Flat bundle-adjustment problem (same field meaning as include/pcdhip.h pcd_ba_desc)."""
+
+    def __init__(self, cam_model, cam_params_list, poses, image_camera, points, obs_image, obs_point, obs_xy,
+                 lidar_point=None, lidar_abcd=None, lidar_weight=None, image_const_pose=None,
+                 image_const_tvec=None, point_const=None, loss_type=0, loss_scale=1.0):
+        self.cam_model = np.ascontiguousarray(cam_model, np.int32)
+        offs, flat = [], []
+        for cp in cam_params_list:
+            offs.append(len(flat))
+            flat.extend(list(cp))
+        self.cam_param_off = np.ascontiguousarray(offs, np.int32)
+        self.cam_params = np.ascontiguousarray(flat, np.float64)
+        self.poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        self.image_camera = np.ascontiguousarray(image_camera, np.int32)
+        self.points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        self.obs_image = np.ascontiguousarray(obs_image, np.int32)
+        self.obs_point = np.ascontiguousarray(obs_point, np.int32)
+        self.obs_xy = np.ascontiguousarray(obs_xy, np.float64).reshape(-1, 2)
+        nl = 0 if lidar_point is None else len(lidar_point)
+        self.lidar_point = np.ascontiguousarray(lidar_point if nl else [], np.int32)
+        self.lidar_abcd = np.ascontiguousarray(lidar_abcd if nl else [], np.float64).reshape(-1, 4)
+        self.lidar_weight = np.ascontiguousarray(lidar_weight if nl else [], np.float64)
+        I, P = self.poses.shape[0], self.points.shape[0]
+        self.image_const_pose = np.ascontiguousarray(
+            image_const_pose if image_const_pose is not None else np.zeros(I), np.uint8)
+        self.image_const_tvec = np.ascontiguousarray(
+            image_const_tvec if image_const_tvec is not None else np.zeros(I), np.uint8)
+        self.point_const = np.ascontiguousarray(point_const if point_const is not None else np.zeros(P), np.uint8)
+        self.loss_type, self.loss_scale = int(loss_type), float(loss_scale)
+        self.stride = max(NUM_PARAMS[m] for m in self.cam_model)
+        p = BAProblem()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        p.num_cameras = len(self.cam_model); p.cam_model = vp(self.cam_model)
+        p.cam_param_off = vp(self.cam_param_off); p.cam_params = vp(self.cam_params)
+        p.num_images = I; p.poses = vp(self.poses); p.image_camera = vp(self.image_camera)
+        p.image_const_pose = vp(self.image_const_pose); p.image_const_tvec = vp(self.image_const_tvec)
+        p.num_points = P; p.points = vp(self.points); p.point_const = vp(self.point_const)
+        p.num_obs = len(self.obs_image); p.obs_image = vp(self.obs_image); p.obs_point = vp(self.obs_point)
+        p.obs_xy = vp(self.obs_xy)
+        p.num_lidar = nl; p.lidar_point = vp(self.lidar_point); p.lidar_abcd = vp(self.lidar_abcd)
+        p.lidar_weight = vp(self.lidar_weight)
+        p.loss_type = self.loss_type; p.loss_scale = self.loss_scale; p.cam_jac_stride = self.stride
+        self._p = p
+
+    def evaluate_raw(self):
+        O, Lc, S = len(self.obs_image), len(self.lidar_point), self.stride
+        res = np.zeros(2 * O + Lc); Jq = np.zeros((O, 2, 4)); Jt = np.zeros((O, 2, 3)); JX = np.zeros((O, 2, 3))
+        Jc = np.zeros((O, 2, S)); JL = np.zeros((Lc, 3))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        lib().oracle_ba_evaluate_raw(C.byref(self._p), vp(res), vp(Jq), vp(Jt), vp(JX), vp(Jc), vp(JL))
+        return res, Jq, Jt, JX, Jc, JL
+
+    def normal_equations(self, want_w=False):
+        I, P, O = self.poses.shape[0], self.points.shape[0], len(self.obs_image)
+        Himg = np.zeros((I, 6, 6)); gimg = np.zeros((I, 6)); Hpt = np.zeros((P, 3, 3)); gpt = np.zeros((P, 3))
+        W = np.zeros((O, 6, 3)) if want_w else None
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        cost = lib().oracle_ba_normal_equations(C.byref(self._p), vp(Himg), vp(gimg), vp(Hpt), vp(gpt), vp(W))
+        return cost, Himg, gimg, Hpt, gpt, W

@@ -1,0 +1,49 @@
+"""Generates the small committed fixtures under tests/golden/ with the CPU oracle.
+
+Run in the build container:  python tests/golden/make_golden.py
+The reference itself cannot be built or run here (PCL / FLANN / Ceres / Eigen absent), so these
+vectors pin the oracle's own outputs; the reference's own known answers are kept separately in
+cost_function_kats.json (values transcribed from src/base/cost_functions_test.cc:41-104).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "colmap-pcd_amd"))
+from oracle import pyoracle as po  # noqa: E402
+from pcdhip import synth  # noqa: E402
+
+
+def nn_small():
+    xyz, nrm = synth.cloud_planes(6000, seed=31, patches=5)
+    xyz[3000:3100] = xyz[100:200]                       # exact duplicates -> ties
+    nrm[50] = 0.0                                       # zero normal -> ply.cc:101 reject
+    q = synth.queries(xyz, 600, seed=77, sigma=0.3)
+    q[:40] = xyz[3000:3040].astype(np.float64)          # tie queries: lowest index (100..139) must win
+    q[40] = [np.nan, 0, 0]
+    q[41] = [1e30, 0, 0]
+    q[42] = xyz[50]
+    idx, sq, found = po.nn_bruteforce(xyz, q)
+    ki, ks, kf = po.KDTree(xyz).query(q)
+    assert np.array_equal(idx, ki) and np.array_equal(sq.view(np.uint32), ks.view(np.uint32)) and np.array_equal(found, kf)
+    assert (idx[:40] == np.arange(100, 140)).all()
+    np.savez_compressed(os.path.join(HERE, "nn_small.npz"), xyz=xyz, nrm=nrm, q=q, idx=idx,
+                        sqdist_bits=sq.view(np.uint32), found=found)
+    # association for the three call sites
+    out6, ok = po.search_nearest_neibor(xyz, nrm, idx, found)
+    mr = synth.max_range_schedule(q.shape[0], seed=5)
+    res = {}
+    for mode in (0, 1, 2):
+        abcd, typ, dist, ang, d2p = po.associate(q, out6, ok, None if mode == 2 else mr, mode)
+        res[f"abcd{mode}"], res[f"type{mode}"], res[f"dist{mode}"], res[f"angle{mode}"], res[f"d2p{mode}"] = \
+            abcd, typ, dist, ang, d2p
+    np.savez_compressed(os.path.join(HERE, "assoc_small.npz"), out6=out6, ok=ok, max_range=mr, **res)
+
+
+if __name__ == "__main__":
+    nn_small()
+    print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

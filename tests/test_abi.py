@@ -1,0 +1,63 @@
+"""CPU-side checks of the drop-in boundary: libpcdhip.so loads, exports every symbol that
+include/pcdhip.h declares, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "pcdhip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcd_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported(pcdhip):
+    lib = pcdhip.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, f"declared in pcdhip.h but not exported: {missing}"
+    assert sorted(pcdhip.ABI_SYMBOLS) == declared
+
+
+def test_version_and_camera_table(pcdhip):
+    lib = pcdhip.lib()
+    assert lib.pcd_version() == 1
+    # CameraModel::kNumParams, base/camera_models.h:187-347
+    assert [lib.pcd_camera_num_params(i) for i in range(11)] == [3, 4, 4, 5, 8, 8, 12, 5, 4, 5, 12]
+    assert lib.pcd_camera_num_params(11) == -1
+
+
+def test_search_range_schedule_matches_oracle(pcdhip, oracle):
+    # sfm/incremental_mapper.cc:1159-1163 defaults 1.5 / 0.2 / 0.1 (controllers/incremental_mapper.h:64-66)
+    opt = np.arange(0, 20, dtype=np.int32)
+    got = pcdhip.search_range_schedule(opt)
+    exp = oracle.search_range_schedule(opt)
+    assert np.array_equal(got, exp)
+    assert got[0] == 1.5 and got[-1] == 0.2 and abs(got[5] - 1.0) < 1e-12
+
+
+def test_no_cpu_fallback_without_gpu(pcdhip):
+    """On a box without a gfx950 device the product path must refuse to run."""
+    if pcdhip.device_count() > 0:
+        pytest.skip("a GPU is present; the refusal path is exercised on CPU-only boxes")
+    xyz = np.zeros((4, 3), np.float32)
+    with pytest.raises(pcdhip.PcdError) as e:
+        pcdhip.Cloud(xyz, xyz, raw_lidar_frame=False)
+    assert e.value.status == pcdhip.PCD_ERR_NO_DEVICE
+
+
+def test_product_does_not_import_oracle():
+    """oracle/ is test infrastructure: nothing under colmap-pcd_amd/ may reference it."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "colmap-pcd_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cc", ".cpp", "Makefile")):
+                if re.search(r"\boracle\b", open(os.path.join(dp, f), errors="ignore").read()):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,102 @@
+"""GPU parity of the fused plane-association epilogue against the CPU oracle.
+
+Reference: lidar/ply.cc:95-101, lidar/lidar_point.cc:5-50, optim/bundle_adjustment.cc:358-410,
+sfm/incremental_mapper.cc:1413-1469, controllers/bundle_adjustment.cc:130-185.
+Bar: type / accept decisions identical; doubles within 1e-12 relative (north_star allows 1e-6;
+the same operation order runs on both sides so they normally agree to the last bit).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from pcdhip import synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+
+def _compare(out, exp_out6, exp_ok, exp, mode):
+    abcd, typ, dist, ang, d2p = exp
+    assert np.array_equal(out["type"], typ), f"mode {mode}: type mismatch at {np.nonzero(out['type'] != typ)[0][:10]}"
+    okm = exp_ok.astype(bool)
+    np.testing.assert_allclose(out["lidar_xyz"][okm], exp_out6[okm, :3], rtol=0, atol=0)
+    np.testing.assert_allclose(out["abcd"], abcd, rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(out["dist"], dist, rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(out["angle"], ang, rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(out["dist2plane"], d2p, rtol=RTOL, atol=1e-15)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_assoc_parity(gpu, oracle, mode):
+    xyz, nrm = synth.cloud_planes(60000, seed=20240601, patches=20)
+    nrm[::97] = 0.0                      # ||n|| < 1e-6 -> SearchNearestNeiborByKdtree returns false
+    nrm[5::101, 0] = 0.0                 # ny/nx = inf passes the ground test
+    nrm[7::103] = [0.0, 1.0, 0.0]        # inf and inf -> ground
+    nrm[11::107] = [0.0, 0.0, 1.0]       # 0/0 = NaN fails -> Icp
+    q = synth.queries(xyz, 20000, seed=99)
+    mr = synth.max_range_schedule(q.shape[0])
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    out = c.associate(q, None if mode == 2 else mr, mode)
+    idx, sq, found = oracle.nn_bruteforce(xyz, q)
+    assert np.array_equal(out["nn_idx"], idx) and np.array_equal(out["nn_sqdist"].view(np.uint32), sq.view(np.uint32))
+    out6, ok = oracle.search_nearest_neibor(xyz, nrm, idx, found)
+    exp = oracle.associate(q, out6, ok, None if mode == 2 else mr, mode)
+    _compare(out, out6, ok, exp, mode)
+    assert (out["type"] == 2).sum() > 100 and (out["type"] == 1).sum() > 100 and (out["type"] == 0).sum() > 100
+    # scalar max_range broadcast
+    if mode != 2:
+        out1 = c.associate(q, 0.7, mode)
+        exp1 = oracle.associate(q, out6, ok, 0.7, mode)
+        _compare(out1, out6, ok, exp1, mode)
+    c.close()
+
+
+def test_assoc_golden(gpu):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "nn_small.npz"))
+    a = np.load(os.path.join(os.path.dirname(__file__), "golden", "assoc_small.npz"))
+    c = gpu.Cloud(g["xyz"], g["nrm"], raw_lidar_frame=False)
+    for mode in (0, 1, 2):
+        out = c.associate(g["q"], None if mode == 2 else a["max_range"], mode)
+        _compare(out, a["out6"], a["ok"], (a[f"abcd{mode}"], a[f"type{mode}"], a[f"dist{mode}"], a[f"angle{mode}"],
+                                            a[f"d2p{mode}"]), mode)
+    c.close()
+
+
+def test_sharded_cloud_min_and_payload(gpu, oracle):
+    """cloud split in 3 interleaved shards on one device: element-wise MIN of the keys + SUM of the
+    winner payload bit patterns must reproduce the single-cloud association exactly (the N-GPU path,
+    minus the collective, which tests/test_distributed.py covers with gloo)."""
+    import torch
+    xyz, nrm = synth.cloud_planes(30000, seed=3, patches=10)
+    q = synth.queries(xyz, 5000, seed=4)
+    Q = q.shape[0]
+    S = 3
+    shards = [gpu.Cloud(xyz[s::S], nrm[s::S], raw_lidar_frame=False, index_base=s, index_stride=S) for s in range(S)]
+    dq = torch.from_numpy(q).cuda()
+    keys = [torch.empty(Q, dtype=torch.int64, device="cuda") for _ in range(S)]
+    for s in range(S):
+        shards[s].nn_device(dq, Q, keys[s])
+    kmin = torch.stack(keys).min(dim=0).values
+    payload = torch.zeros(Q, 6, dtype=torch.int32, device="cuda")
+    for s in range(S):
+        p = torch.empty(Q, 6, dtype=torch.int32, device="cuda")
+        shards[s].winner_payload_device(kmin, Q, p)
+        payload += p
+    torch.cuda.synchronize()
+    idx, sq, found = oracle.nn_bruteforce(xyz, q)
+    k = kmin.cpu().numpy().astype(np.uint64)
+    assert np.array_equal((k & 0xFFFFFFFF).astype(np.uint32), idx)
+    assert np.array_equal((k >> 32).astype(np.uint32), sq.view(np.uint32))
+    d = {n: torch.empty(s, dtype=t, device="cuda") for n, s, t in
+         [("lidar_xyz", (Q, 3), torch.float64), ("abcd", (Q, 4), torch.float64), ("type", (Q,), torch.uint8),
+          ("dist", (Q,), torch.float64), ("angle", (Q,), torch.float64), ("dist2plane", (Q,), torch.float64)]}
+    mr = torch.full((1,), 1.0, dtype=torch.float64, device="cuda")
+    gpu.associate_from_payload_device(0, dq, Q, mr, 1, 0, kmin, payload, d)
+    torch.cuda.synchronize()
+    out6, ok = oracle.search_nearest_neibor(xyz, nrm, idx, found)
+    exp = oracle.associate(q, out6, ok, 1.0, 0)
+    out = {n: v.cpu().numpy() for n, v in d.items()}
+    _compare(out, out6, ok, exp, 0)
+    for s in shards:
+        s.close()

@@ -1,0 +1,170 @@
+"""GPU parity of the nearest-neighbour path (through the C ABI) against the CPU oracle.
+
+Bar: bit-exact -- same index, same float32 squared-distance bits, same found flag
+(reference semantics: lidar/kdtree.cc:10-21 + lidar/ply.cc:90-93; ties -> lowest index).
+"""
+import numpy as np
+import pytest
+
+from pcdhip import synth
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = ["AUTO", "BRUTEFORCE", "FALLBACK_ONLY"]
+
+
+def _algo(pcdhip, name):
+    return getattr(pcdhip, "NN_" + name)
+
+
+def _check_exact(got, exp, what=""):
+    gi, gd, gf = got
+    ei, ed, ef = exp
+    assert np.array_equal(gf, ef), f"{what}: found flags differ at {np.nonzero(gf != ef)[0][:10]}"
+    bad = np.nonzero((gi != ei) | (gd.view(np.uint32) != ed.view(np.uint32)))[0]
+    assert bad.size == 0, (f"{what}: {bad.size} mismatches, first {bad[:5]}: idx {gi[bad[:5]]} vs {ei[bad[:5]]}, "
+                           f"d {gd[bad[:5]]} vs {ed[bad[:5]]}")
+
+
+def _clouds():
+    rng = np.random.default_rng(3)
+    out = {}
+    out["uniform"] = synth.cloud_uniform(40000, seed=7, box=np.array([20.0, 5.0, 20.0]))
+    out["planes"] = synth.cloud_planes(50000, seed=20240601, patches=24)
+    # duplicates (exact ties) + clustered points
+    x, n = synth.cloud_uniform(20000, seed=8, box=np.array([10.0, 10.0, 10.0]))
+    x[5000:10000] = x[0:5000]
+    x[15000:] = x[15000] + rng.normal(0, 1e-3, (5000, 3)).astype(np.float32)
+    out["duplicates"] = (x, n)
+    return out
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("name", ["uniform", "planes", "duplicates"])
+def test_nn_parity_small(gpu, oracle, name, algo):
+    xyz, nrm = _clouds()[name]
+    q = synth.queries(xyz, 4000, seed=99)
+    # some queries exactly on cloud points (ties among duplicates -> lowest index must win)
+    q[:200] = xyz[np.random.default_rng(1).integers(0, xyz.shape[0], 200)].astype(np.float64)
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    got = c.nn(q, _algo(gpu, algo))
+    exp = oracle.nn_bruteforce(xyz, q)
+    _check_exact(got, exp, f"{name}/{algo}")
+    c.close()
+
+
+@pytest.mark.parametrize("cell", [0.05, 0.3, 2.0, 50.0])
+def test_nn_parity_any_cell_size(gpu, oracle, cell):
+    """exactness must not depend on the grid resolution (pruning is conservative)"""
+    xyz, nrm = synth.cloud_planes(30000, seed=5, patches=12)
+    q = synth.queries(xyz, 3000, seed=17, sigma=0.6)
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False, cell_size=cell)
+    exp = oracle.nn_bruteforce(xyz, q)
+    for algo in ("AUTO", "FALLBACK_ONLY"):
+        _check_exact(c.nn(q, _algo(gpu, algo)), exp, f"cell={cell}/{algo}")
+    c.close()
+
+
+def test_raw_frame_transform_and_nan_rows(gpu, oracle):
+    """lidar/ply.cc:33-57: axis swap, rows with any NaN dropped, order kept; indices are post-filter."""
+    xyz_v, nrm_v = synth.cloud_uniform(5000, seed=21, box=np.array([8.0, 3.0, 8.0]))
+    raw_xyz, raw_nrm = synth.visual_to_raw(xyz_v, nrm_v)
+    rng = np.random.default_rng(4)
+    raw_xyz[rng.integers(0, 5000, 60), rng.integers(0, 3, 60)] = np.nan
+    raw_nrm[rng.integers(0, 5000, 40), rng.integers(0, 3, 40)] = np.nan
+    exp_xyz, exp_nrm = oracle.direction_trans(raw_xyz, raw_nrm)
+    c = gpu.Cloud(raw_xyz, raw_nrm, raw_lidar_frame=True)
+    assert len(c) == exp_xyz.shape[0] < 5000
+    got_xyz, got_nrm = c.download()
+    assert np.array_equal(got_xyz.view(np.uint32), exp_xyz.view(np.uint32))
+    assert np.array_equal(got_nrm.view(np.uint32), exp_nrm.view(np.uint32))
+    q = synth.queries(exp_xyz, 1500, seed=2)
+    _check_exact(c.nn(q), oracle.nn_bruteforce(exp_xyz, q), "raw frame")
+    # AoS32 layout of lidarpt::Point (lidar/pt_type.h:14-30)
+    aos = np.zeros((5000, 8), np.float32)
+    aos[:, 0:3] = raw_xyz
+    aos[:, 4:7] = raw_nrm
+    c2 = gpu.Cloud(aos, layout=gpu.LAYOUT_AOS32, raw_lidar_frame=True)
+    assert len(c2) == len(c)
+    _check_exact(c2.nn(q), oracle.nn_bruteforce(exp_xyz, q), "aos32")
+    c.close(); c2.close()
+
+
+def test_edge_cases(gpu, oracle):
+    z3 = np.zeros((0, 3), np.float32)
+    q = np.array([[0.0, 0, 0], [1e30, 0, 0], [np.nan, 0, 0], [np.inf, 1, 1], [1e-40, -1e-40, 0]])
+    # empty cloud: Kdtree::GetClosestPoint returns false
+    c = gpu.Cloud(z3, z3, raw_lidar_frame=False)
+    for a in ALGOS:
+        i, d, f = c.nn(q, _algo(gpu, a))
+        assert not f.any() and (i == 0xFFFFFFFF).all()
+    assert c.nn(np.zeros((0, 3)))[0].shape == (0,)
+    c.close()
+    # all rows NaN -> empty after the filter
+    allnan = np.full((7, 3), np.nan, np.float32)
+    c = gpu.Cloud(allnan, allnan, raw_lidar_frame=True)
+    assert len(c) == 0 and not c.nn(q)[2].any()
+    c.close()
+    # single point, Inf rows keep their index but never win, far / non-finite queries
+    xyz = np.array([[np.inf, 0, 0], [1.0, 2.0, 3.0], [0, -np.inf, 0], [1.0, 2.0, 3.0]], np.float32)
+    c = gpu.Cloud(xyz, np.ones_like(xyz), raw_lidar_frame=False)
+    exp = oracle.nn_bruteforce(xyz, q)
+    for a in ALGOS:
+        _check_exact(c.nn(q, _algo(gpu, a)), exp, f"edge/{a}")
+    i, d, f = c.nn(q)
+    assert list(f) == [1, 0, 0, 0, 1] and i[0] == 1 and i[4] == 1   # 1e30: squared distance overflows -> not found
+    c.close()
+    # degenerate extents: all points on a line / in one cell
+    line = np.zeros((3000, 3), np.float32)
+    line[:, 0] = np.linspace(0, 30, 3000)
+    c = gpu.Cloud(line, np.ones_like(line), raw_lidar_frame=False)
+    qq = synth.queries(line, 500, seed=3, sigma=2.0)
+    for a in ALGOS:
+        _check_exact(c.nn(qq, _algo(gpu, a)), oracle.nn_bruteforce(line, qq), f"line/{a}")
+    c.close()
+
+
+def test_queries_outside_bbox_and_far(gpu, oracle):
+    xyz, nrm = synth.cloud_planes(20000, seed=9, patches=6)
+    rng = np.random.default_rng(12)
+    q = (rng.random((2000, 3)) - 0.5) * 600.0      # mostly far outside the cloud's bounding box
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    exp = oracle.nn_bruteforce(xyz, q)
+    for a in ALGOS:
+        _check_exact(c.nn(q, _algo(gpu, a)), exp, f"far/{a}")
+    c.close()
+
+
+def test_golden_fixture(gpu):
+    """committed vectors (tests/golden/make_golden.py, produced with the CPU oracle)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "nn_small.npz"))
+    c = gpu.Cloud(g["xyz"], g["nrm"], raw_lidar_frame=False)
+    for a in ALGOS:
+        i, d, f = c.nn(g["q"], _algo(gpu, a))
+        assert np.array_equal(i, g["idx"]) and np.array_equal(d.view(np.uint32), g["sqdist_bits"])
+        assert np.array_equal(f, g["found"])
+    c.close()
+
+
+def test_midsize_vs_kdtree_oracle_and_gpu_bruteforce(gpu, oracle):
+    """2 M points / 200 k queries: grid kernels == GPU brute force everywhere, == exact CPU KD-tree on a sample,
+    plus size-independent properties (returned distance is the distance to the returned index; no staged or
+    sampled point is closer)."""
+    xyz, nrm = synth.cloud_planes(2_000_000, seed=20240601)
+    q = synth.queries(xyz, 200_000, seed=99)
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    gi, gd, gf = c.nn(q)
+    bi, bd, bf = c.nn(q[:20000], gpu.NN_BRUTEFORCE)
+    _check_exact((gi[:20000], gd[:20000], gf[:20000]), (bi, bd, bf), "grid vs gpu brute force")
+    kd = oracle.KDTree(xyz)
+    sel = np.random.default_rng(0).choice(q.shape[0], 20000, replace=False)
+    _check_exact((gi[sel], gd[sel], gf[sel]), kd.query(q[sel]), "grid vs cpu kd-tree")
+    # property: sqdist is exactly the float distance to the returned point
+    qf = q.astype(np.float32)
+    p = xyz[gi]
+    dx, dy, dz = qf[:, 0] - p[:, 0], qf[:, 1] - p[:, 1], qf[:, 2] - p[:, 2]
+    d = (dx * dx + dy * dy) + dz * dz
+    assert np.array_equal(d.view(np.uint32), gd.view(np.uint32))
+    st = c.last_stats()
+    c.close()
