@@ -1,0 +1,447 @@
+// ba.hip -- bundle-adjustment residual / Jacobian / normal-equation evaluation.
+//
+// Replaces the work ceres::Solve performs per iteration on the problem assembled by
+// optim/bundle_adjustment.cc:694-1131 (AddImageToProblem, AddImageInSphereToProblem,
+// AddPointToProblem, AddLidarToProblem, ParameterizeCameras/Points): every residual block's
+// CostFunction::Evaluate (base/cost_functions.h:49-141, :150-241, :256-370), the loss
+// correction (optim/bundle_adjustment.cc:53-68) and the manifold projection
+// (base/cost_functions.h:610-627), then J^T J / J^T r block accumulation.
+//
+// Kernels (all fp64, HBM-bound: ~300 flop per ~60-200 B per observation):
+//   k_ba_points  thread = 3D point (track): walks the point's observations and LiDAR terms,
+//                accumulates its 3x3 block, gradient and the cost.  No atomics: point blocks are
+//                complete inside one thread, the cost goes through a fixed-order two-stage sum.
+//   k_ba_images  workgroup = image: its observations (CSR list) are strided over 256 lanes, each
+//                lane recomputes the 2x6 pose-tangent Jacobian and accumulates 21 + 6 unique
+//                entries; block reduction in a fixed order -> deterministic 6x6 block + gradient.
+//   k_ba_raw     thread = observation / LiDAR term: the raw ambient blocks exactly as
+//                CostFunction::Evaluate returns them (for the Ceres EvaluationCallback adapter).
+// Jacobians are recomputed in each kernel instead of being staged through HBM: 160 B/obs of
+// Jacobian traffic would cost more than the ~300 flops.
+#include <algorithm>
+#include <numeric>
+
+#include "ba_math.h"
+#include "common.h"
+
+namespace pcd {
+
+struct BaDev {
+  // problem (device)
+  const int* cam_model; const int* cam_off; const double* cam_params;
+  const double* poses; const int* image_cam; const uint8_t* image_const_pose; const uint8_t* image_const_tvec;
+  const double* points; const uint8_t* point_const;
+  const int* obs_image; const int* obs_point; const double* obs_xy;
+  const int* lidar_point; const double* lidar_abcd; const double* lidar_w;
+  // CSR
+  const uint32_t* pt_obs_start; const uint32_t* pt_obs_list;
+  const uint32_t* pt_lidar_start; const uint32_t* pt_lidar_list;
+  const uint32_t* img_obs_start; const uint32_t* img_obs_list;
+  int I, P; uint64_t O, L;
+  int loss_type; double loss_scale;
+};
+
+__device__ __forceinline__ void load_obs_block(const BaDev& d, uint32_t o, ReprojBlock& b, int& im, int& pt,
+                                               double q[4]) {
+  im = d.obs_image[o];
+  pt = d.obs_point[o];
+  const double* pose = d.poses + 7 * (size_t)im;
+  double t[3], X[3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) q[k] = pose[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { t[k] = pose[4 + k]; X[k] = d.points[3 * (size_t)pt + k]; }
+  const int cm = d.image_cam[im];
+  reproj_eval(d.cam_model[cm], d.cam_params + d.cam_off[cm], q, t, X, d.obs_xy[2 * (size_t)o],
+              d.obs_xy[2 * (size_t)o + 1], b);
+}
+
+// ------------------------------------------------------------- points ------
+__global__ __launch_bounds__(256) void k_ba_points(BaDev d, double* __restrict__ Hpt, double* __restrict__ gpt,
+                                                   double* __restrict__ cost_partial) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  double cost = 0.0;
+  if (p < d.P) {
+    double H[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    const bool cpt = d.point_const && d.point_const[p];
+    for (uint32_t e = d.pt_obs_start[p]; e < d.pt_obs_start[p + 1]; ++e) {
+      const uint32_t o = d.pt_obs_list[e];
+      ReprojBlock b;
+      int im, pt;
+      double q[4];
+      load_obs_block(d, o, b, im, pt, q);
+      double rho0, rho1;
+      loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
+      cost += 0.5 * rho0;
+      if (!cpt) {
+        const double sr = sqrt(rho1);
+        double J[6];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            J[3 * r + k] = sr * (b.M[3 * r] * b.D[k] + b.M[3 * r + 1] * b.D[3 + k] + b.M[3 * r + 2] * b.D[6 + k]);
+        const double r0 = sr * b.r[0], r1 = sr * b.r[1];
+        H[0] += J[0] * J[0] + J[3] * J[3]; H[1] += J[0] * J[1] + J[3] * J[4]; H[2] += J[0] * J[2] + J[3] * J[5];
+        H[3] += J[1] * J[1] + J[4] * J[4]; H[4] += J[1] * J[2] + J[4] * J[5]; H[5] += J[2] * J[2] + J[5] * J[5];
+        g[0] += J[0] * r0 + J[3] * r1; g[1] += J[1] * r0 + J[4] * r1; g[2] += J[2] * r0 + J[5] * r1;
+      }
+    }
+    const double X[3] = {d.points[3 * (size_t)p], d.points[3 * (size_t)p + 1], d.points[3 * (size_t)p + 2]};
+    for (uint32_t e = d.pt_lidar_start[p]; e < d.pt_lidar_start[p + 1]; ++e) {
+      const uint32_t l = d.pt_lidar_list[e];
+      const double abcd[4] = {d.lidar_abcd[4 * (size_t)l], d.lidar_abcd[4 * (size_t)l + 1],
+                              d.lidar_abcd[4 * (size_t)l + 2], d.lidar_abcd[4 * (size_t)l + 3]};
+      double r, J[3];
+      lidar_eval(X, abcd, d.lidar_w[l], 0, r, J);
+      double rho0, rho1;
+      loss_eval(d.loss_type, d.loss_scale, r * r, rho0, rho1);
+      cost += 0.5 * rho0;
+      if (!cpt) {
+        const double sr = sqrt(rho1);
+        const double rc = sr * r;
+        J[0] *= sr; J[1] *= sr; J[2] *= sr;
+        H[0] += J[0] * J[0]; H[1] += J[0] * J[1]; H[2] += J[0] * J[2];
+        H[3] += J[1] * J[1]; H[4] += J[1] * J[2]; H[5] += J[2] * J[2];
+        g[0] += J[0] * rc; g[1] += J[1] * rc; g[2] += J[2] * rc;
+      }
+    }
+    if (Hpt) {
+      double* h = Hpt + 9 * (size_t)p;
+      h[0] = H[0]; h[1] = H[1]; h[2] = H[2]; h[3] = H[1]; h[4] = H[3]; h[5] = H[4]; h[6] = H[2]; h[7] = H[4]; h[8] = H[5];
+    }
+    if (gpt) { gpt[3 * (size_t)p] = g[0]; gpt[3 * (size_t)p + 1] = g[1]; gpt[3 * (size_t)p + 2] = g[2]; }
+  }
+  // fixed-order block sum of the cost
+  __shared__ double s_c[256];
+  s_c[threadIdx.x] = cost;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_c[threadIdx.x] += s_c[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cost_partial[blockIdx.x] = s_c[0];
+}
+
+// observations whose point is not listed (cannot happen) need no handling; the final cost sum:
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int n, double* __restrict__ out) {
+  __shared__ double s_c[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  s_c[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_c[threadIdx.x] += s_c[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = s_c[0];
+}
+
+// ------------------------------------------------------------- images ------
+__global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__ Himg, double* __restrict__ gimg) {
+  const int im = blockIdx.x;
+  const bool cpose = d.image_const_pose && d.image_const_pose[im];
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+  if (!cpose) {
+    const unsigned tmask = d.image_const_tvec ? d.image_const_tvec[im] : 0u;
+    for (uint32_t e = d.img_obs_start[im] + threadIdx.x; e < d.img_obs_start[im + 1]; e += 256) {
+      const uint32_t o = d.img_obs_list[e];
+      ReprojBlock b;
+      int im2, pt;
+      double q[4];
+      load_obs_block(d, o, b, im2, pt, q);
+      double rho0, rho1;
+      loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
+      const double sr = sqrt(rho1);
+      double Jq[8], Jt[6], JX[6], Jqt[6];
+      reproj_jacobians(b, Jq, Jt, JX);
+      quat_tangent(q, Jq, Jqt);
+      double J[12];  // 2 x 6
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          J[6 * r + k] = sr * Jqt[3 * r + k];
+          J[6 * r + 3 + k] = ((tmask >> k) & 1u) ? 0.0 : sr * Jt[3 * r + k];
+        }
+      const double r0 = sr * b.r[0], r1 = sr * b.r[1];
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = a; c < 6; ++c) acc[idx++] += J[a] * J[c] + J[6 + a] * J[6 + c];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r0 + J[6 + a] * r1;
+    }
+  }
+  // fixed-order reduction: wave butterfly, then the 4 waves through LDS
+  __shared__ double s_a[4][27];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) s_a[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const double v = (s_a[0][threadIdx.x] + s_a[1][threadIdx.x]) + (s_a[2][threadIdx.x] + s_a[3][threadIdx.x]);
+    if (threadIdx.x >= 21) {
+      if (gimg) gimg[6 * (size_t)im + (threadIdx.x - 21)] = v;
+    } else if (Himg) {
+      // unpack the upper triangle index
+      int a = 0, k = threadIdx.x;
+      while (k >= 6 - a) { k -= 6 - a; ++a; }
+      const int c = a + k;
+      Himg[36 * (size_t)im + 6 * a + c] = v;
+      Himg[36 * (size_t)im + 6 * c + a] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- raw ------
+__global__ __launch_bounds__(256) void k_ba_raw(BaDev d, double* __restrict__ residuals, double* __restrict__ Jq_o,
+                                                double* __restrict__ Jt_o, double* __restrict__ JX_o,
+                                                double* __restrict__ W_o) {
+  const uint64_t o = blockIdx.x * (uint64_t)256 + threadIdx.x;
+  if (o >= d.O) return;
+  ReprojBlock b;
+  int im, pt;
+  double q[4];
+  load_obs_block(d, (uint32_t)o, b, im, pt, q);
+  double Jq[8], Jt[6], JX[6];
+  reproj_jacobians(b, Jq, Jt, JX);
+  const bool cpose = d.image_const_pose && d.image_const_pose[im];
+  if (residuals) { residuals[2 * o] = b.r[0]; residuals[2 * o + 1] = b.r[1]; }
+  if (Jq_o) for (int k = 0; k < 8; ++k) Jq_o[8 * o + k] = cpose ? 0.0 : Jq[k];
+  if (Jt_o) for (int k = 0; k < 6; ++k) Jt_o[6 * o + k] = cpose ? 0.0 : Jt[k];
+  if (JX_o) for (int k = 0; k < 6; ++k) JX_o[6 * o + k] = JX[k];
+  if (W_o) {
+    double rho0, rho1;
+    loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
+    const double sr = sqrt(rho1);
+    const unsigned tmask = d.image_const_tvec ? d.image_const_tvec[im] : 0u;
+    const bool cpt = d.point_const && d.point_const[pt];
+    double Jqt[6], J[12], Jx[6];
+    quat_tangent(q, Jq, Jqt);
+    for (int r = 0; r < 2; ++r)
+      for (int k = 0; k < 3; ++k) {
+        J[6 * r + k] = cpose ? 0.0 : sr * Jqt[3 * r + k];
+        J[6 * r + 3 + k] = (cpose || ((tmask >> k) & 1u)) ? 0.0 : sr * Jt[3 * r + k];
+        Jx[3 * r + k] = cpt ? 0.0 : sr * JX[3 * r + k];
+      }
+    for (int a = 0; a < 6; ++a)
+      for (int c = 0; c < 3; ++c) W_o[18 * o + 3 * a + c] = J[a] * Jx[c] + J[6 + a] * Jx[3 + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ba_lidar_raw(BaDev d, double* __restrict__ residuals, double* __restrict__ JL) {
+  const uint64_t l = blockIdx.x * (uint64_t)256 + threadIdx.x;
+  if (l >= d.L) return;
+  const int p = d.lidar_point[l];
+  const double X[3] = {d.points[3 * (size_t)p], d.points[3 * (size_t)p + 1], d.points[3 * (size_t)p + 2]};
+  const double abcd[4] = {d.lidar_abcd[4 * l], d.lidar_abcd[4 * l + 1], d.lidar_abcd[4 * l + 2], d.lidar_abcd[4 * l + 3]};
+  double r, J[3];
+  lidar_eval(X, abcd, d.lidar_w[l], 0, r, J);
+  if (residuals) residuals[2 * d.O + l] = r;
+  if (JL) { JL[3 * l] = J[0]; JL[3 * l + 1] = J[1]; JL[3 * l + 2] = J[2]; }
+}
+
+}  // namespace pcd
+
+using namespace pcd;
+
+struct pcd_ba {
+  int device = 0;
+  int C = 0, I = 0, P = 0;
+  uint64_t O = 0, L = 0;
+  int loss_type = 0;
+  double loss_scale = 1.0;
+  DevBuf<int> cam_model, cam_off, image_cam, obs_image, obs_point, lidar_point;
+  DevBuf<double> cam_params, poses, points, obs_xy, lidar_abcd, lidar_w;
+  DevBuf<uint8_t> image_const_pose, image_const_tvec, point_const;
+  bool has_cpose = false, has_ctvec = false, has_cpt = false;
+  DevBuf<uint32_t> pt_obs_start, pt_obs_list, pt_lidar_start, pt_lidar_list, img_obs_start, img_obs_list;
+  DevBuf<double> cost_partial, cost;
+  // host-API staging
+  DevBuf<double> o_res, o_jq, o_jt, o_jx, o_jl, o_himg, o_gimg, o_hpt, o_gpt, o_w;
+  BaDev dev() const {
+    BaDev d;
+    d.cam_model = cam_model.p; d.cam_off = cam_off.p; d.cam_params = cam_params.p;
+    d.poses = poses.p; d.image_cam = image_cam.p;
+    d.image_const_pose = has_cpose ? image_const_pose.p : nullptr;
+    d.image_const_tvec = has_ctvec ? image_const_tvec.p : nullptr;
+    d.points = points.p; d.point_const = has_cpt ? point_const.p : nullptr;
+    d.obs_image = obs_image.p; d.obs_point = obs_point.p; d.obs_xy = obs_xy.p;
+    d.lidar_point = lidar_point.p; d.lidar_abcd = lidar_abcd.p; d.lidar_w = lidar_w.p;
+    d.pt_obs_start = pt_obs_start.p; d.pt_obs_list = pt_obs_list.p;
+    d.pt_lidar_start = pt_lidar_start.p; d.pt_lidar_list = pt_lidar_list.p;
+    d.img_obs_start = img_obs_start.p; d.img_obs_list = img_obs_list.p;
+    d.I = I; d.P = P; d.O = O; d.L = L; d.loss_type = loss_type; d.loss_scale = loss_scale;
+    return d;
+  }
+};
+
+template <typename T>
+static pcd_status upload(DevBuf<T>& b, const T* src, size_t n) {
+  PCD_TRY(b.reserve(std::max<size_t>(n, 1)));
+  if (n) PCD_HIP_TRY(hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return PCD_OK;
+}
+
+// stable counting sort of element ids by key -> CSR (start[nkeys+1], list[n])
+static void build_csr(const int32_t* key, uint64_t n, int nkeys, std::vector<uint32_t>& start,
+                      std::vector<uint32_t>& list) {
+  start.assign((size_t)nkeys + 1, 0);
+  for (uint64_t i = 0; i < n; ++i) start[(size_t)key[i] + 1]++;
+  for (int k = 0; k < nkeys; ++k) start[k + 1] += start[k];
+  list.resize(n);
+  std::vector<uint32_t> cur(start.begin(), start.end() - 1);
+  for (uint64_t i = 0; i < n; ++i) list[cur[key[i]]++] = (uint32_t)i;
+}
+
+extern "C" {
+
+pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
+  PCD_REQUIRE(d && out, "null pointer");
+  *out = nullptr;
+  PCD_REQUIRE(d->camera_refine == nullptr, "refining intrinsics is not implemented (reference default: constant)");
+  if (d->camera_refine) return PCD_ERR_UNSUPPORTED;
+  PCD_REQUIRE(d->num_cameras > 0 && d->cam_model && d->cam_param_offset && d->cam_params, "cameras");
+  PCD_REQUIRE(d->num_images > 0 && d->poses && d->image_camera, "images");
+  PCD_REQUIRE(d->num_points > 0 && d->points, "points");
+  PCD_REQUIRE(d->num_obs == 0 || (d->obs_image && d->obs_point && d->obs_xy), "observations");
+  PCD_REQUIRE(d->num_lidar == 0 || (d->lidar_point && d->lidar_abcd && d->lidar_weight), "lidar terms");
+  PCD_REQUIRE(d->loss_type >= 0 && d->loss_type <= 2, "loss_type");
+  PCD_REQUIRE(d->loss_type == PCD_LOSS_TRIVIAL || d->loss_scale > 0, "loss_scale");
+  PCD_REQUIRE(d->num_obs < 0xFFFFFFF0ull && d->num_lidar < 0xFFFFFFF0ull, "too many residual blocks");
+  for (int c = 0; c < d->num_cameras; ++c) {
+    const int k = pcd_camera_num_params(d->cam_model[c]);
+    PCD_REQUIRE(k > 0, "unknown camera model id");  // reference: std::domain_error, camera_models.h:140
+    PCD_REQUIRE(d->cam_param_offset[c] >= 0 && (uint64_t)d->cam_param_offset[c] + k <= d->cam_params_len,
+                "camera parameter offsets");
+  }
+  for (int i = 0; i < d->num_images; ++i)
+    PCD_REQUIRE(d->image_camera[i] >= 0 && d->image_camera[i] < d->num_cameras, "image_camera out of range");
+  for (uint64_t o = 0; o < d->num_obs; ++o) {
+    PCD_REQUIRE(d->obs_image[o] >= 0 && d->obs_image[o] < d->num_images, "obs_image out of range");
+    PCD_REQUIRE(d->obs_point[o] >= 0 && d->obs_point[o] < d->num_points, "obs_point out of range");
+  }
+  for (uint64_t l = 0; l < d->num_lidar; ++l)
+    PCD_REQUIRE(d->lidar_point[l] >= 0 && d->lidar_point[l] < d->num_points, "lidar_point out of range");
+  PCD_TRY(require_device(d->device));
+
+  pcd_ba* b = new pcd_ba();
+  b->device = d->device;
+  b->C = d->num_cameras; b->I = d->num_images; b->P = d->num_points; b->O = d->num_obs; b->L = d->num_lidar;
+  b->loss_type = d->loss_type; b->loss_scale = d->loss_scale;
+  auto fail = [&](pcd_status st) { pcd_ba_destroy(b); return st; };
+#define UP(buf, src, n) do { pcd_status _st = upload(b->buf, src, (size_t)(n)); if (_st != PCD_OK) return fail(_st); } while (0)
+  UP(cam_model, d->cam_model, b->C); UP(cam_off, d->cam_param_offset, b->C); UP(cam_params, d->cam_params, d->cam_params_len);
+  UP(poses, d->poses, 7 * (size_t)b->I); UP(image_cam, d->image_camera, b->I);
+  UP(points, d->points, 3 * (size_t)b->P);
+  UP(obs_image, d->obs_image, b->O); UP(obs_point, d->obs_point, b->O); UP(obs_xy, d->obs_xy, 2 * b->O);
+  UP(lidar_point, d->lidar_point, b->L); UP(lidar_abcd, d->lidar_abcd, 4 * b->L); UP(lidar_w, d->lidar_weight, b->L);
+  if (d->image_const_pose) { b->has_cpose = true; UP(image_const_pose, d->image_const_pose, b->I); }
+  if (d->image_const_tvec) { b->has_ctvec = true; UP(image_const_tvec, d->image_const_tvec, b->I); }
+  if (d->point_const) { b->has_cpt = true; UP(point_const, d->point_const, b->P); }
+  std::vector<uint32_t> st, li;
+  build_csr(d->obs_point, b->O, b->P, st, li);
+  UP(pt_obs_start, st.data(), st.size()); UP(pt_obs_list, li.data(), li.size());
+  build_csr(d->lidar_point, b->L, b->P, st, li);
+  UP(pt_lidar_start, st.data(), st.size()); UP(pt_lidar_list, li.data(), li.size());
+  build_csr(d->obs_image, b->O, b->I, st, li);
+  UP(img_obs_start, st.data(), st.size()); UP(img_obs_list, li.data(), li.size());
+#undef UP
+  pcd_status s1 = b->cost_partial.reserve(div_up(b->P, 256));
+  if (s1 != PCD_OK) return fail(s1);
+  if ((s1 = b->cost.reserve(1)) != PCD_OK) return fail(s1);
+  *out = b;
+  return PCD_OK;
+}
+
+void pcd_ba_destroy(pcd_ba* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  delete b;
+}
+
+pcd_status pcd_ba_set_parameters(pcd_ba* b, const double* poses, const double* points) {
+  PCD_REQUIRE(b, "null handle");
+  PCD_HIP_TRY(hipSetDevice(b->device));
+  if (poses) PCD_HIP_TRY(hipMemcpy(b->poses.p, poses, 7 * (size_t)b->I * sizeof(double), hipMemcpyHostToDevice));
+  if (points) PCD_HIP_TRY(hipMemcpy(b->points.p, points, 3 * (size_t)b->P * sizeof(double), hipMemcpyHostToDevice));
+  return PCD_OK;
+}
+
+pcd_status pcd_ba_device_parameters(pcd_ba* b, double** d_poses, double** d_points) {
+  PCD_REQUIRE(b, "null handle");
+  if (d_poses) *d_poses = b->poses.p;
+  if (d_points) *d_points = b->points.p;
+  return PCD_OK;
+}
+
+pcd_status pcd_ba_evaluate_device(pcd_ba* b, const pcd_ba_out* o, void* stream) {
+  PCD_REQUIRE(b && o, "null pointer");
+  PCD_HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  const BaDev d = b->dev();
+  if (o->cost || o->H_pt || o->g_pt) {
+    const unsigned blocks = div_up(b->P, 256);
+    {
+      ScopedKernelTimer t("ba_points", s);
+      hipLaunchKernelGGL(k_ba_points, dim3(blocks), dim3(256), 0, s, d, o->H_pt, o->g_pt, b->cost_partial.p);
+    }
+    if (o->cost) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, b->cost_partial.p, (int)blocks, o->cost);
+  }
+  if (o->H_img || o->g_img) {
+    ScopedKernelTimer t("ba_images", s);
+    hipLaunchKernelGGL(k_ba_images, dim3(b->I), dim3(256), 0, s, d, o->H_img, o->g_img);
+  }
+  if ((o->residuals || o->jac_q || o->jac_t || o->jac_X || o->W) && b->O) {
+    ScopedKernelTimer t("ba_raw", s);
+    hipLaunchKernelGGL(k_ba_raw, dim3(div_up(b->O, 256)), dim3(256), 0, s, d, o->residuals, o->jac_q, o->jac_t,
+                       o->jac_X, o->W);
+  }
+  if ((o->residuals || o->jac_lidar) && b->L) {
+    ScopedKernelTimer t("ba_lidar_raw", s);
+    hipLaunchKernelGGL(k_ba_lidar_raw, dim3(div_up(b->L, 256)), dim3(256), 0, s, d, o->residuals, o->jac_lidar);
+  }
+  PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
+
+pcd_status pcd_ba_evaluate(pcd_ba* b, const pcd_ba_out* o) {
+  PCD_REQUIRE(b && o, "null pointer");
+  PCD_HIP_TRY(hipSetDevice(b->device));
+  pcd_ba_out d{};
+  struct Item { double* host; DevBuf<double>* buf; size_t n; double** slot; };
+  Item items[] = {
+      {o->cost, &b->cost, 1, &d.cost},
+      {o->residuals, &b->o_res, 2 * b->O + b->L, &d.residuals},
+      {o->jac_q, &b->o_jq, 8 * b->O, &d.jac_q},
+      {o->jac_t, &b->o_jt, 6 * b->O, &d.jac_t},
+      {o->jac_X, &b->o_jx, 6 * b->O, &d.jac_X},
+      {o->jac_lidar, &b->o_jl, 3 * b->L, &d.jac_lidar},
+      {o->H_img, &b->o_himg, 36 * (size_t)b->I, &d.H_img},
+      {o->g_img, &b->o_gimg, 6 * (size_t)b->I, &d.g_img},
+      {o->H_pt, &b->o_hpt, 9 * (size_t)b->P, &d.H_pt},
+      {o->g_pt, &b->o_gpt, 3 * (size_t)b->P, &d.g_pt},
+      {o->W, &b->o_w, 18 * b->O, &d.W},
+  };
+  for (auto& it : items)
+    if (it.host) {
+      PCD_TRY(it.buf->reserve(std::max<size_t>(it.n, 1)));
+      *it.slot = it.buf->p;
+    }
+  PCD_TRY(pcd_ba_evaluate_device(b, &d, nullptr));
+  for (auto& it : items)
+    if (it.host && it.n) PCD_HIP_TRY(hipMemcpy(it.host, it.buf->p, it.n * sizeof(double), hipMemcpyDeviceToHost));
+  PCD_HIP_TRY(hipDeviceSynchronize());
+  return PCD_OK;
+}
+
+}  // extern "C"

@@ -7,7 +7,8 @@
 //   sorted [m] float4 {x,y,z,bits(global_idx)}  finite rows in cell-sorted order (x fastest):
 //              one 16-B record per lane per load; a row of cells along x is one contiguous range
 //   cell_start [ncells+1] uint32    exclusive prefix of per-cell counts
-//   blk_aabb [nblocks][8] float     tight bounds {lo.xyz, hi.xyz, 0, 0} of every 4x4x4-cell block
+//   blk_aabb [nodes][8] float       tight bounds {lo.xyz, hi.xyz, 0, 0}: every 4x4x4-cell block (level 0)
+//                                   followed by the coarser pyramid levels (4x4x4 children each)
 #pragma once
 #include "common.h"
 
@@ -23,6 +24,15 @@ struct GridParams {
   float slack;    // metres: bound on binning rounding, see nn.hip
 };
 
+// 64-ary AABB pyramid over the blocks: level 0 = blocks, level k+1 = 4x4x4 nodes of level k,
+// top level = one node.  All levels live in blk_aabb (8 floats per node) at off[level].
+constexpr int kMaxPyrLevels = 10;
+struct PyramidParams {
+  int nlev;                       // >= 2
+  int dims[kMaxPyrLevels][3];
+  uint32_t off[kMaxPyrLevels];    // node offset of each level
+};
+
 struct QueryScratch;  // nn.hip
 
 }  // namespace pcd
@@ -36,6 +46,7 @@ struct pcd_cloud {
   pcd::DevBuf<uint32_t> cell_start;
   pcd::DevBuf<float> blk_aabb;
   pcd::GridParams grid{};
+  pcd::PyramidParams pyr{};
   uint64_t ncells = 0, nblocks = 0, occupied = 0;
   double build_ms = 0;
   pcd::QueryScratch* scratch = nullptr;

@@ -170,6 +170,25 @@ __global__ void k_block_aabb(const float4* __restrict__ sorted, const uint32_t* 
   }
 }
 
+// pyramid level k+1 from level k: union of the <= 64 children boxes (empty = {+inf, -inf})
+__global__ void k_pyramid_level(float* __restrict__ aabb, uint32_t off_child, int cdx, int cdy, int cdz,
+                                uint32_t off_parent, int pdx, int pdy, int pdz) {
+  const uint64_t id = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (id >= (uint64_t)pdx * pdy * pdz) return;
+  const int px = (int)(id % pdx), py = (int)((id / pdx) % pdy), pz = (int)(id / ((uint64_t)pdx * pdy));
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < 4; ++i) {
+        const int cx = 4 * px + i, cy = 4 * py + j, cz = 4 * pz + k;
+        if (cx >= cdx || cy >= cdy || cz >= cdz) continue;
+        const float* a = aabb + 8 * ((uint64_t)off_child + ((uint64_t)cz * cdy + cy) * cdx + cx);
+        for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], a[d]); hi[d] = fmaxf(hi[d], a[3 + d]); }
+      }
+  float* o = aabb + 8 * ((uint64_t)off_parent + id);
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.f; o[7] = 0.f;
+}
+
 // ------------------------------------------------------------ host side ----
 static void set_dims(GridParams& g, const float lo[3], const float hi[3], float h) {
   g.h = h;
@@ -306,10 +325,31 @@ static pcd_status build_grid(pcd_cloud* c, float user_h, hipStream_t s) {
     PCD_HIP_TRY(hipStreamSynchronize(s));
   }
 
-  // --- tight block bounds ---
-  PCD_TRY(c->blk_aabb.reserve(8 * c->nblocks));
+  // --- tight block bounds + coarser pyramid levels ---
+  PyramidParams& py = c->pyr;
+  py.nlev = 1;
+  for (int d = 0; d < 3; ++d) py.dims[0][d] = g.bdims[d];
+  py.off[0] = 0;
+  uint64_t total_nodes = c->nblocks;
+  while (py.nlev < kMaxPyrLevels) {
+    const int* pd = py.dims[py.nlev - 1];
+    const bool single = pd[0] == 1 && pd[1] == 1 && pd[2] == 1;
+    if (single && py.nlev >= 2) break;
+    for (int d = 0; d < 3; ++d) py.dims[py.nlev][d] = (pd[d] + 3) / 4;
+    py.off[py.nlev] = (uint32_t)total_nodes;
+    total_nodes += (uint64_t)py.dims[py.nlev][0] * py.dims[py.nlev][1] * py.dims[py.nlev][2];
+    py.nlev++;
+  }
+  PCD_TRY(c->blk_aabb.reserve(8 * total_nodes));
   hipLaunchKernelGGL(k_block_aabb, dim3(div_up(c->nblocks * 64, 256)), dim3(256), 0, s, c->sorted.p,
                      c->cell_start.p, g, c->nblocks, c->blk_aabb.p);
+  for (int l = 1; l < py.nlev; ++l) {
+    const int* cd = py.dims[l - 1];
+    const int* pd = py.dims[l];
+    const uint64_t np = (uint64_t)pd[0] * pd[1] * pd[2];
+    hipLaunchKernelGGL(k_pyramid_level, dim3(div_up(np, 256)), dim3(256), 0, s, c->blk_aabb.p, py.off[l - 1], cd[0],
+                       cd[1], cd[2], py.off[l], pd[0], pd[1], pd[2]);
+  }
   PCD_HIP_TRY(hipStreamSynchronize(s));
   PCD_HIP_TRY(hipGetLastError());
   return PCD_OK;

@@ -356,114 +356,101 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, ui
   }
 }
 
-// ring rho >= 1 around (0,0,0): t in [0, ring_cells(rho)) -> offset
-__device__ __forceinline__ void ring_offset(int rho, int t, int& dx, int& dy, int& dz) {
-  const int w = 2 * rho + 1, face = w * w;
-  if (t < 2 * face) {
-    dz = t < face ? -rho : rho;
-    const int r = t < face ? t : t - face;
-    dx = r % w - rho;
-    dy = r / w - rho;
-  } else {
-    const int u0 = t - 2 * face, per = 8 * rho;
-    dz = -rho + 1 + u0 / per;
-    const int u = u0 % per, side = u / (2 * rho), k = u % (2 * rho);
-    if (side == 0) { dx = -rho + k; dy = -rho; }
-    else if (side == 1) { dx = rho; dy = -rho + k; }
-    else if (side == 2) { dx = rho - k; dy = rho; }
-    else { dx = -rho; dy = rho - k; }
-  }
-}
-
-__global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, const float4* __restrict__ sorted,
+// One wavefront per query walks the 64-ary AABB pyramid over the grid (level 0 = 4x4x4-cell blocks,
+// level k+1 = 4x4x4 nodes of level k): the 64 children of the current node sit one per lane, each
+// lane computes the exact float lower bound of its child, and the wave descends into the nearest
+// child whose bound does not exceed the best distance so far (depth first, nearest first).
+// Every skipped subtree has bound > best, so the result is the exact minimum of the packed keys.
+__global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams py, const float4* __restrict__ sorted,
                                                       const uint32_t* __restrict__ cell_start,
-                                                      const float* __restrict__ blk_aabb,
+                                                      const float* __restrict__ aabb,
                                                       const float4* __restrict__ qf4,
                                                       const uint32_t* __restrict__ list,  // NULL: queries 0..count-1
                                                       const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
                                                       uint64_t* __restrict__ keys, NnCounters* __restrict__ ctr,
                                                       int collect_stats) {
+  __shared__ float s_lb[4][kMaxPyrLevels][64];
+  __shared__ unsigned long long s_mask[4][kMaxPyrLevels];
+  __shared__ int s_node[4][kMaxPyrLevels][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t count = count_ptr ? *count_ptr : count_imm;
   const uint32_t nwaves = gridDim.x * 4;
+  const int top = py.nlev - 1;  // >= 1
+  const int ci = lane & 3, cj = (lane >> 2) & 3, ck = lane >> 4;
   unsigned long long st_pts = 0, st_q = 0;
   for (uint32_t e = blockIdx.x * 4 + wave; e < count; e += nwaves) {
     const uint32_t qi = list ? list[e] : e;
     const float4 q = qf4[qi];
     if (q.w == 0.f) continue;  // not finite: stays "not found"
     const float qx = q.x, qy = q.y, qz = q.z;
-    uint64_t best = keys[qi];          // kKeyInit or the brick kernel's tentative result
+    uint64_t best = keys[qi];  // kKeyInit or the brick kernel's tentative result
     uint64_t lane_best = best;
-    const int mb[3] = {cell_coord(qx, g.origin[0], g.inv_h, g.dims[0]) / kBlockCells,
-                       cell_coord(qy, g.origin[1], g.inv_h, g.dims[1]) / kBlockCells,
-                       cell_coord(qz, g.origin[2], g.inv_h, g.dims[2]) / kBlockCells};
-    const int maxrho = max(max(g.bdims[0], g.bdims[1]), g.bdims[2]);
-    for (int rho = 0; rho <= maxrho; ++rho) {
-      const int ncell = rho == 0 ? 1 : 2 * (2 * rho + 1) * (2 * rho + 1) + (2 * rho - 1) * 8 * rho;
-      for (int t0 = 0; t0 < ncell; t0 += 64) {
-        const int t = t0 + lane;
-        bool cand = false;
-        float lb = 0.f;
-        int bx = 0, by = 0, bz = 0;
-        if (t < ncell) {
-          int dx = 0, dy = 0, dz = 0;
-          if (rho) ring_offset(rho, t, dx, dy, dz);
-          bx = mb[0] + dx; by = mb[1] + dy; bz = mb[2] + dz;
-          if (bx >= 0 && bx < g.bdims[0] && by >= 0 && by < g.bdims[1] && bz >= 0 && bz < g.bdims[2]) {
-            const uint64_t blk = ((uint64_t)bz * g.bdims[1] + by) * g.bdims[0] + bx;
-            const float4 lo = *reinterpret_cast<const float4*>(blk_aabb + 8 * blk);
-            const float4 hi = *reinterpret_cast<const float4*>(blk_aabb + 8 * blk + 4);
-            // stored as {lo.x lo.y lo.z hi.x | hi.y hi.z 0 0}
-            if (lo.x <= lo.w) {  // non-empty
-              const float cx = fminf(fmaxf(qx, lo.x), lo.w), cy = fminf(fmaxf(qy, lo.y), hi.x),
-                          cz = fminf(fmaxf(qz, lo.z), hi.y);
-              lb = l2_simple3(qx, qy, qz, cx, cy, cz);
-              cand = true;
-            }
+    float best_d = __uint_as_float((uint32_t)(best >> 32));
+    int lev = top;
+    int nx = 0, ny = 0, nz = 0;
+    bool expand = true;
+    while (true) {
+      if (expand) {
+        // children of node (nx,ny,nz) of level `lev` live on level lev-1
+        const int cx = 4 * nx + ci, cy = 4 * ny + cj, cz = 4 * nz + ck;
+        const int* dm = py.dims[lev - 1];
+        float lb = INFINITY;
+        if (cx < dm[0] && cy < dm[1] && cz < dm[2]) {
+          const uint64_t id = py.off[lev - 1] + ((uint64_t)cz * dm[1] + cy) * dm[0] + cx;
+          const float4 lo = *reinterpret_cast<const float4*>(aabb + 8 * id);      // lo.x lo.y lo.z hi.x
+          const float4 hi = *reinterpret_cast<const float4*>(aabb + 8 * id + 4);  // hi.y hi.z 0 0
+          if (lo.x <= lo.w) {
+            const float px = fminf(fmaxf(qx, lo.x), lo.w), pyc = fminf(fmaxf(qy, lo.y), hi.x),
+                        pz = fminf(fmaxf(qz, lo.z), hi.y);
+            lb = l2_simple3(qx, qy, qz, px, pyc, pz);
           }
         }
-        float best_d = __uint_as_float((uint32_t)(best >> 32));
-        cand = cand && (lb <= best_d);
-        // nearest candidate block first; re-prune the others after every block
-        while (true) {
-          const uint64_t sel = wave_min_u64(cand ? (((uint64_t)__float_as_uint(lb) << 32) | (uint32_t)lane) : ~0ull);
-          if (sel == ~0ull) break;
-          const int sl = (int)(sel & 63);
-          const int sbx = __shfl(bx, sl), sby = __shfl(by, sl), sbz = __shfl(bz, sl);
-          // the block's 16 rows (4 cells along x each): lanes 0..15 fetch the ranges
-          uint32_t rs = 0, re = 0;
-          if (lane < kBlockCells * kBlockCells) {
-            const int cy = sby * kBlockCells + (lane & 3), cz = sbz * kBlockCells + (lane >> 2);
-            if (cy < g.dims[1] && cz < g.dims[2]) {
-              const int cx0 = sbx * kBlockCells, cx1 = min(cx0 + kBlockCells, g.dims[0]);
-              const uint64_t rowbase = ((uint64_t)cz * g.dims[1] + cy) * g.dims[0];
-              rs = cell_start[rowbase + cx0];
-              re = cell_start[rowbase + cx1];
-            }
+        s_lb[wave][lev][lane] = lb;
+        const unsigned long long m = __ballot(lb <= best_d);
+        if (lane == 0) { s_mask[wave][lev] = m; s_node[wave][lev][0] = nx; s_node[wave][lev][1] = ny; s_node[wave][lev][2] = nz; }
+        expand = false;
+      }
+      const float lb = s_lb[wave][lev][lane];
+      unsigned long long m = s_mask[wave][lev] & __ballot(lb <= best_d);
+      if (m == 0) {
+        if (lev == top) break;
+        ++lev;
+        continue;
+      }
+      const bool cand = (m >> lane) & 1ull;
+      const uint64_t sel = wave_min_u64(cand ? (((uint64_t)__float_as_uint(lb) << 32) | (uint32_t)lane) : ~0ull);
+      const int sl = (int)(sel & 63);
+      m &= ~(1ull << sl);
+      if (lane == 0) s_mask[wave][lev] = m;
+      nx = 4 * s_node[wave][lev][0] + (sl & 3);
+      ny = 4 * s_node[wave][lev][1] + ((sl >> 2) & 3);
+      nz = 4 * s_node[wave][lev][2] + (sl >> 4);
+      if (lev == 1) {
+        // (nx,ny,nz) is a block: its 16 rows of 4 cells along x are contiguous ranges
+        uint32_t rs = 0, re = 0;
+        if (lane < kBlockCells * kBlockCells) {
+          const int cy = ny * kBlockCells + (lane & 3), cz = nz * kBlockCells + (lane >> 2);
+          if (cy < g.dims[1] && cz < g.dims[2]) {
+            const int cx0 = nx * kBlockCells, cx1 = min(cx0 + kBlockCells, g.dims[0]);
+            const uint64_t rowbase = ((uint64_t)cz * g.dims[1] + cy) * g.dims[0];
+            rs = cell_start[rowbase + cx0];
+            re = cell_start[rowbase + cx1];
           }
-          unsigned long long rows = __ballot(re > rs);
-          while (rows) {
-            const int r = __ffsll((long long)rows) - 1;
-            rows &= rows - 1;
-            const uint32_t a = __shfl(rs, r), bnd = __shfl(re, r);
-            scan_range(sorted, a, bnd, qx, qy, qz, lane_best);
-            st_pts += bnd - a;
-          }
-          best = wave_min_u64(lane_best);
-          best_d = __uint_as_float((uint32_t)(best >> 32));
-          if (lane == sl) cand = false;
-          cand = cand && (lb <= best_d);
         }
+        unsigned long long rows = __ballot(re > rs);
+        while (rows) {
+          const int r = __ffsll((long long)rows) - 1;
+          rows &= rows - 1;
+          const uint32_t a = __shfl(rs, r), bnd = __shfl(re, r);
+          scan_range(sorted, a, bnd, qx, qy, qz, lane_best);
+          st_pts += bnd - a;
+        }
+        best = wave_min_u64(lane_best);
+        best_d = __uint_as_float((uint32_t)(best >> 32));
+      } else {
+        --lev;
+        expand = true;
       }
-      // everything within Chebyshev block distance rho is done: provably final?
-      int c0[3], c1[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        c0[d] = max((mb[d] - rho) * kBlockCells, 0);
-        c1[d] = min((mb[d] + rho + 1) * kBlockCells, g.dims[d]);
-      }
-      const double bound = proven_bound(g, qx, qy, qz, c0, c1);
-      if ((double)__uint_as_float((uint32_t)(best >> 32)) < bound) break;
     }
     if (lane == 0) keys[qi] = best;
     st_q += 1;
@@ -520,7 +507,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   {
     ScopedKernelTimer t("nn_fallback", s);
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), 256 * 8);
-    hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, g, c->sorted.p, c->cell_start.p,
+    hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, g, c->pyr, c->sorted.p, c->cell_start.p,
                        c->blk_aabb.p, sc->qf4.p, sc->fb_list.p, &sc->counters.p->fb_count, 0u, d_keys,
                        sc->counters.p, g_collect_stats);
   }
@@ -553,7 +540,7 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
       PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
       ScopedKernelTimer t("nn_fallback", s);
       const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), 256 * 8);
-      hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, c->grid, c->sorted.p, c->cell_start.p,
+      hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, c->grid, c->pyr, c->sorted.p, c->cell_start.p,
                          c->blk_aabb.p, sc->qf4.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)Q,
                          d_keys, sc->counters.p, g_collect_stats);
     } else if (algo == PCD_NN_AUTO) {

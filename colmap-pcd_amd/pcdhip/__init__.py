@@ -106,6 +106,14 @@ def lib():
         return _LIB
     if not os.path.exists(LIB_PATH):
         raise PcdError(PCD_ERR_NO_DEVICE, f"{LIB_PATH} not built; run __graft_entry__.build() or make -C colmap-pcd_amd")
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.7 / libhsa-runtime64.
+    # If libpcdhip pulled in /opt/rocm's copy first, torch would later mix the two and find no GPU, so
+    # when torch is installed let it load its runtime first; libpcdhip then binds to the same soname.
+    if os.environ.get("PCDHIP_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     L.pcd_last_error.restype = C.c_char_p
     L.pcd_cloud_size.restype = C.c_uint64
