@@ -1,0 +1,279 @@
+// brick_kernel.h -- the LDS-tiled brick kernel of the NN search (included by nn.hip).
+//
+// One wavefront per work item = (brick of B^3 cells, <= G queries whose home cell lies in it).
+// The cell rows of the brick grown by R cells are contiguous ranges of the cell-sorted cloud; their
+// concatenation is streamed through two 256-point LDS tiles per wavefront:
+//   * staging is LDS-DMA (global_load_lds_dwordx4: one 16-B record per lane, no VGPR round trip);
+//     the 4 DMAs of tile t+1 are in flight while tile t is compared (counted s_waitcnt vmcnt(4));
+//   * compare: lanes = staged points (ds_read_b128), the G queries are wave-uniform (SGPRs), every
+//     point is tested against every query with FLANN's float arithmetic, per-lane running minima of
+//     the packed (distance, index) keys;
+//   * one transposed butterfly reduces all G per-lane minima at once (reduce-scatter over
+//     xor 32/16/8, then xor 4/2/1), instead of G separate wavefront reductions;
+//   * work items are software-pipelined: the item record of group k+2 and the query / row-range
+//     loads of group k+1 are issued before group k is processed.
+// A query is final when best < (distance to the staged region's boundary)^2 (nn.hip header); the
+// others go to the exact fallback with their tentative key as starting bound.
+#pragma once
+
+namespace pcd {
+
+constexpr int kTile = 256;  // points per LDS tile buffer (4 KiB); two buffers per wavefront
+
+__device__ __forceinline__ void lds_dma16(const float4* gsrc, float4* lds_wave_base) {
+  // LDS destination = wave-uniform base + lane * 16 (hardware adds the lane offset)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+  const uint32_t lo = __shfl_xor((uint32_t)v, m), hi = __shfl_xor((uint32_t)(v >> 32), m);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b) { return b < a ? b : a; }
+
+// All-lanes minimum of 8 per-lane values at once.  Returns, in every lane, the minimum of value
+// index ((lane>>5)&1)*4 + ((lane>>4)&1)*2 + ((lane>>3)&1).
+__device__ __forceinline__ uint64_t wave_min8_u64(const uint64_t (&v)[8]) {
+  const int lane = threadIdx.x & 63;
+  uint64_t a[4], b2[2], c;
+  {
+    const bool up = lane & 32;  // upper half keeps 4..7, sends 0..3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint64_t keep = up ? v[4 + i] : v[i], send = up ? v[i] : v[4 + i];
+      a[i] = min_u64(keep, shfl_xor_u64(send, 32));
+    }
+  }
+  {
+    const bool up = lane & 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint64_t keep = up ? a[2 + i] : a[i], send = up ? a[i] : a[2 + i];
+      b2[i] = min_u64(keep, shfl_xor_u64(send, 16));
+    }
+  }
+  {
+    const bool up = lane & 8;
+    const uint64_t keep = up ? b2[1] : b2[0], send = up ? b2[0] : b2[1];
+    c = min_u64(keep, shfl_xor_u64(send, 8));
+  }
+  c = min_u64(c, shfl_xor_u64(c, 4));
+  c = min_u64(c, shfl_xor_u64(c, 2));
+  c = min_u64(c, shfl_xor_u64(c, 1));
+  return c;
+}
+
+struct BrickMeta {   // per-group loads issued one group ahead
+  float4 q;          // lane < cnt: query (x,y,z, bits(query id))
+  uint32_t s, e;     // lane < nrows: point range of the lane's cell row
+};
+
+// item record: {first query, brick x, brick y, brick z | count << 28}
+__device__ __forceinline__ int item_count(const uint4 it) { return (int)(it.w >> 28); }
+
+__device__ __forceinline__ void brick_region(const GridParams& g, const BrickParams& b, const uint4 it, int c0[3],
+                                             int c1[3]) {
+  const int bx = (int)it.y, by = (int)it.z, bz = (int)(it.w & 0x0FFFFFFFu);
+  c0[0] = max(bx * b.B - b.R, 0); c0[1] = max(by * b.B - b.R, 0); c0[2] = max(bz * b.B - b.R, 0);
+  c1[0] = min(bx * b.B + b.B + b.R, g.dims[0]); c1[1] = min(by * b.B + b.B + b.R, g.dims[1]);
+  c1[2] = min(bz * b.B + b.B + b.R, g.dims[2]);
+}
+
+__device__ __forceinline__ BrickMeta brick_load_meta(const GridParams& g, const BrickParams& b, const uint4 it,
+                                                     const float4* __restrict__ qsorted,
+                                                     const uint32_t* __restrict__ cell_start) {
+  const int lane = threadIdx.x & 63;
+  BrickMeta m;
+  // Every lane issues every load (indices clamped, results masked afterwards): a load under a
+  // divergent `if` may be branched around, and then hipcc can no longer count the loads in flight and
+  // falls back to s_waitcnt vmcnt(0) at the first use -- which would serialise the prefetch.
+  const int cnt = item_count(it);  // >= 1
+  m.q = qsorted[it.x + (lane < cnt ? lane : cnt - 1)];
+  int c0[3], c1[3];
+  brick_region(g, b, it, c0, c1);
+  const int ny = c1[1] - c0[1], nrows = ny * (c1[2] - c0[2]);  // 1 <= ny <= 8, nrows <= 64
+  const int row = lane < nrows ? lane : nrows - 1;
+  // row / ny without an integer division: ceil(2^16 / ny) is exact for row < 64, ny <= 8
+  const uint32_t inv = ny == 1 ? 65536u : ny == 2 ? 32768u : ny == 3 ? 21846u : ny == 4 ? 16384u
+                     : ny == 5 ? 13108u : ny == 6 ? 10923u : ny == 7 ? 9363u : 8192u;
+  const int rz = (int)(((uint32_t)row * inv) >> 16), ry = row - rz * ny;
+  const int cy = c0[1] + ry, cz = c0[2] + rz;
+  const uint64_t rowbase = ((uint64_t)cz * g.dims[1] + cy) * g.dims[0];
+  m.s = cell_start[rowbase + c0[0]];
+  m.e = cell_start[rowbase + c1[0]];
+  if (lane >= nrows) m.e = m.s;  // empty row
+  return m;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_nn_brick(GridParams g, BrickParams b, const float4* __restrict__ sorted,
+                                                  const uint32_t* __restrict__ cell_start,
+                                                  const float4* __restrict__ qsorted,
+                                                  const uint4* __restrict__ items, NnCounters* __restrict__ ctr,
+                                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ fb_list,
+                                                  int collect_stats) {
+  static_assert(kTile == 256, "the asm tile read is written for 4 x 64 records");
+  static_assert(G == 8, "the transposed reduction is written for 8 queries per group");
+  __shared__ __attribute__((aligned(16))) float4 s_tile[4][2][kTile];
+  __shared__ uint32_t s_rowoff[4][kMaxRows];
+  __shared__ uint32_t s_rowsrc[4][kMaxRows];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* rowoff = s_rowoff[wave];
+  uint32_t* rowsrc = s_rowsrc[wave];
+  const uint32_t nitems = ctr->nitems;
+  const uint32_t nwaves = gridDim.x * 4;
+  unsigned long long st_staged = 0, st_pairs = 0, st_groups = 0;
+
+  // XCD-aware work split: blocks b, b+8, b+16, ... share an XCD (and its 4 MiB L2), so each of the 8
+  // block classes walks its own contiguous eighth of the item list (items are in brick order, x fastest):
+  // bricks that are neighbours in space -- and share most of their staged rows -- meet in one L2.
+  // (speed only: any mapping gives the same results.)
+  uint32_t item, item_end, stride;
+  if ((gridDim.x & 7u) == 0) {
+    const uint32_t cls = blockIdx.x & 7u, per = (nitems + 7u) / 8u;
+    stride = (gridDim.x >> 3) * 4;
+    item = cls * per + (blockIdx.x >> 3) * 4 + wave;
+    item_end = min(nitems, (cls + 1) * per);
+  } else {
+    stride = nwaves;
+    item = blockIdx.x * 4 + wave;
+    item_end = nitems;
+  }
+  if (item >= item_end) return;
+  uint4 it0 = items[item];
+  BrickMeta m0 = brick_load_meta(g, b, it0, qsorted, cell_start);
+  uint4 it1 = items[min(item + stride, item_end - 1)];
+
+  for (; item < item_end; item += stride) {
+    // ---- prefetch: metadata of the next group, item record of the one after ----
+    // (unconditional, clamped to the last item: see brick_load_meta)
+    const BrickMeta m1 = brick_load_meta(g, b, it1, qsorted, cell_start);
+    const uint4 it2 = items[min(item + 2 * stride, item_end - 1)];
+
+    // ---- current group ----
+    const uint32_t cnt = (uint32_t)item_count(it0);
+    float qx[G], qy[G], qz[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const int src = k < (int)cnt ? k : 0;  // empty slots repeat query 0; their results are not written
+      qx[k] = readlane_f(m0.q.x, src);
+      qy[k] = readlane_f(m0.q.y, src);
+      qz[k] = readlane_f(m0.q.z, src);
+    }
+    int c0[3], c1[3];
+    brick_region(g, b, it0, c0, c1);
+    uint32_t T;
+    const uint32_t len = m0.e - m0.s;
+    const uint32_t off = wave_excl_scan_u32(len, T);
+    __builtin_amdgcn_wave_barrier();
+    rowoff[lane] = off;
+    rowsrc[lane] = m0.s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    uint64_t best[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) best[k] = kKeyInit;
+
+    if (T > 0) {
+      const int ntiles = (int)((T + kTile - 1) / kTile);
+      // issue the 4 DMAs of tile t (always exactly 4 instructions: out-of-range lanes re-read element T-1)
+      auto issue_tile = [&](int t) {
+        float4* buf = s_tile[wave][t & 1];
+#pragma unroll
+        for (int k = 0; k < kTile / 64; ++k) {
+          uint32_t gi = (uint32_t)t * kTile + k * 64 + lane;
+          gi = gi < T ? gi : T - 1;
+          int r = 0;
+#pragma unroll
+          for (int step = 32; step > 0; step >>= 1)
+            if (rowoff[r + step] <= gi) r += step;  // largest r with rowoff[r] <= gi (empty rows share offsets)
+          lds_dma16(sorted + (rowsrc[r] + (gi - rowoff[r])), buf + k * 64);
+        }
+      };
+      issue_tile(0);
+      for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) {
+          issue_tile(t + 1);
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile t landed, tile t+1 still in flight
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int tn = (int)min((uint32_t)kTile, T - (uint32_t)t * kTile);
+        // The tile is read with inline-asm ds_read_b128: for an ordinary LDS load hipcc would insert
+        // s_waitcnt vmcnt(0) (it cannot tell the two buffers apart) and drain tile t+1's DMAs.
+        f32x4 p[kTile / 64];
+        const uint32_t rd = lds_addr(s_tile[wave][t & 1]) + lane * 16;
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                     "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
+                     : "v"(rd)
+                     : "memory");
+        // half-filled groups (cnt <= G/2, wave-uniform) skip the empty query slots
+        if (cnt <= G / 2) {
+#pragma unroll
+          for (int k = 0; k < kTile / 64; ++k) {
+            if (k * 64 + lane < tn) {
+              const uint32_t pi = __float_as_uint(p[k].w);
+#pragma unroll
+              for (int qk = 0; qk < G / 2; ++qk) {
+                const float d = l2_simple3(qx[qk], qy[qk], qz[qk], p[k].x, p[k].y, p[k].z);
+                best[qk] = min_u64(best[qk], make_key(d, pi));
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < kTile / 64; ++k) {
+            if (k * 64 + lane < tn) {
+              const uint32_t pi = __float_as_uint(p[k].w);
+#pragma unroll
+              for (int qk = 0; qk < G; ++qk) {
+                const float d = l2_simple3(qx[qk], qy[qk], qz[qk], p[k].x, p[k].y, p[k].z);
+                best[qk] = min_u64(best[qk], make_key(d, pi));
+              }
+            }
+          }
+        }
+        // (the reads of this buffer have returned -- waited inside the asm block -- before tile t+2's DMAs)
+      }
+    }
+    // ---- one transposed reduction for the 8 queries; lane k fetches result k ----
+    const uint64_t red = wave_min8_u64(best);
+    // value index v sits in lanes with bits (5,4,3) = v  ->  lane 8*bitrev... v = b5*4 + b4*2 + b3
+    const int holder = ((lane & 4) ? 32 : 0) | ((lane & 2) ? 16 : 0) | ((lane & 1) ? 8 : 0);
+    const uint64_t mine = ((uint64_t)__shfl((uint32_t)(red >> 32), holder) << 32) | __shfl((uint32_t)red, holder);
+    bool unproven = false;
+    if (lane < (int)cnt) {
+      const uint32_t my_qi = __float_as_uint(m0.q.w);
+      const double bound = proven_bound(g, m0.q.x, m0.q.y, m0.q.z, c0, c1);
+      const double bd = (double)__uint_as_float((uint32_t)(mine >> 32));
+      unproven = !(bd < bound);
+      keys[my_qi] = mine;  // final, or the starting bound of the fallback
+    }
+    const unsigned long long um = __ballot(unproven);
+    if (um) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&ctr->fb_count, (uint32_t)__popcll(um));
+      base = __shfl(base, 0);
+      if (unproven) fb_list[base + __popcll(um & ((1ull << lane) - 1))] = __float_as_uint(m0.q.w);
+    }
+    if (collect_stats) { st_staged += T; st_pairs += (unsigned long long)T * cnt; st_groups += 1; }
+    it0 = it1; it1 = it2; m0 = m1;
+  }
+  if (collect_stats && lane == 0) {
+    atomicAdd(&ctr->staged_points, st_staged);
+    atomicAdd(&ctr->pair_evals, st_pairs);
+    atomicAdd(&ctr->brick_groups, st_groups);
+  }
+}
+
+}  // namespace pcd

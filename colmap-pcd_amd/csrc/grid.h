@@ -37,16 +37,52 @@ __device__ __forceinline__ uint64_t make_key(float d, uint32_t idx) {
   return ((uint64_t)__float_as_uint(d) << 32) | idx;
 }
 
-// wave64 min of a u64 key
+// ---- wave64 scans / reductions on the VALU (DPP), not through the LDS crossbar ----------------
+// gfx9 recipe: row_shr 1,2,4,8 inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3.  Lanes without a source keep the identity (bound_ctrl = false).
+#define PCD_DPP_STEP(OP, V, ID, CTRL, ROWMASK) \
+  V = OP(V, (uint32_t)__builtin_amdgcn_update_dpp((int)(ID), (int)(V), CTRL, ROWMASK, 0xf, false))
+__device__ __forceinline__ uint32_t op_min_u32(uint32_t a, uint32_t b) { return b < a ? b : a; }
+__device__ __forceinline__ uint32_t op_add_u32(uint32_t a, uint32_t b) { return a + b; }
+
+// inclusive prefix minimum; lane 63 holds the minimum of the wave
+__device__ __forceinline__ uint32_t wave_scan_min_u32(uint32_t v) {
+  PCD_DPP_STEP(op_min_u32, v, 0xFFFFFFFFu, 0x111, 0xf);
+  PCD_DPP_STEP(op_min_u32, v, 0xFFFFFFFFu, 0x112, 0xf);
+  PCD_DPP_STEP(op_min_u32, v, 0xFFFFFFFFu, 0x114, 0xf);
+  PCD_DPP_STEP(op_min_u32, v, 0xFFFFFFFFu, 0x118, 0xf);
+  PCD_DPP_STEP(op_min_u32, v, 0xFFFFFFFFu, 0x142, 0xa);
+  PCD_DPP_STEP(op_min_u32, v, 0xFFFFFFFFu, 0x143, 0xc);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_min_u32(v), 63);
+}
+// inclusive prefix sum
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
+  PCD_DPP_STEP(op_add_u32, v, 0u, 0x111, 0xf);
+  PCD_DPP_STEP(op_add_u32, v, 0u, 0x112, 0xf);
+  PCD_DPP_STEP(op_add_u32, v, 0u, 0x114, 0xf);
+  PCD_DPP_STEP(op_add_u32, v, 0u, 0x118, 0xf);
+  PCD_DPP_STEP(op_add_u32, v, 0u, 0x142, 0xa);
+  PCD_DPP_STEP(op_add_u32, v, 0u, 0x143, 0xc);
+  return v;
+}
+
+// wave64 min of a u64 key (distance bits high, index low): two 32-bit DPP reductions
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t k) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    uint32_t lo = __shfl_xor((uint32_t)k, off);
-    uint32_t hi = __shfl_xor((uint32_t)(k >> 32), off);
-    uint64_t o = ((uint64_t)hi << 32) | lo;
-    k = o < k ? o : k;
-  }
-  return k;
+  const uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;
+  const uint32_t mh = wave_min_u32(hi);
+  const uint32_t ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+  return ((uint64_t)mh << 32) | ml;
+}
+
+// lane holding the smallest value among the lanes of `mask` (ties: lowest lane); mask must be != 0
+__device__ __forceinline__ int wave_argmin_u32(uint32_t v, unsigned long long mask) {
+  const bool in = (mask >> (threadIdx.x & 63)) & 1ull;
+  const uint32_t m = wave_min_u32(in ? v : 0xFFFFFFFFu);
+  const unsigned long long hit = __ballot(in && v == m);
+  return __ffsll((long long)(hit ? hit : mask)) - 1;
 }
 
 }  // namespace pcd

@@ -171,26 +171,31 @@ __global__ void k_brick_items_count(unsigned long long* __restrict__ brick_cnt, 
 
 template <int G>
 __global__ void k_brick_emit(const unsigned long long* __restrict__ brick_cnt,
-                             const unsigned long long* __restrict__ brick_off, uint32_t nbricks,
+                             const unsigned long long* __restrict__ brick_off, uint32_t nbricks, uint32_t nb0, uint32_t nb1,
                              uint4* __restrict__ items, NnCounters* __restrict__ ctr) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbricks) return;
   const uint32_t cnt = (uint32_t)(brick_cnt[b] & 0xFFFFFFFFull);
   const uint32_t qoff = (uint32_t)(brick_off[b] & 0xFFFFFFFFull), ioff = (uint32_t)(brick_off[b] >> 32);
   const uint32_t nit = (cnt + G - 1) / G;
+  // item record {first query, brick x, brick y, brick z | count << 28}: the brick kernel needs no divisions
+  const uint32_t bx = b % nb0, by = (b / nb0) % nb1, bz = b / (nb0 * nb1);
   for (uint32_t k = 0; k < nit; ++k)
-    items[ioff + k] = make_uint4(qoff + k * G, b, min((uint32_t)G, cnt - k * G), 0u);
+    items[ioff + k] = make_uint4(qoff + k * G, bx, by, bz | (min((uint32_t)G, cnt - k * G) << 28));
   if (b == nbricks - 1) ctr->nitems = ioff + nit;
 }
 
-__global__ void k_brick_scatter(const uint32_t* __restrict__ brick_of, const uint32_t* __restrict__ rank,
-                                const unsigned long long* __restrict__ brick_off, uint64_t Q,
-                                uint32_t* __restrict__ q_order) {
+// brick-sorted query records {x, y, z, bits(query id)}: the brick kernel reads them with one load
+__global__ void k_brick_scatter(const float4* __restrict__ qf4, const uint32_t* __restrict__ brick_of,
+                                const uint32_t* __restrict__ rank, const unsigned long long* __restrict__ brick_off,
+                                uint64_t Q, float4* __restrict__ qsorted) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= Q) return;
   uint32_t b = brick_of[i];
   if (b == 0xFFFFFFFFu) return;
-  q_order[(uint32_t)(brick_off[b] & 0xFFFFFFFFull) + rank[i]] = (uint32_t)i;
+  float4 q = qf4[i];
+  q.w = __uint_as_float((uint32_t)i);
+  qsorted[(uint32_t)(brick_off[b] & 0xFFFFFFFFull) + rank[i]] = q;
 }
 
 // ------------------------------------------------------------ brick kernel ---
@@ -199,14 +204,8 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t& total) {
-  const int lane = threadIdx.x & 63;
-  uint32_t inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t t = __shfl_up(inc, off);
-    if (lane >= off) inc += t;
-  }
-  total = __shfl(inc, 63);
+  const uint32_t inc = wave_scan_add_u32(v);
+  total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
   return inc - v;
 }
 
@@ -227,8 +226,13 @@ __device__ __forceinline__ double proven_bound(const GridParams& g, float qx, fl
   return margin * margin * (1.0 - 1e-6);
 }
 
+}  // namespace pcd
+#include "brick_kernel.h"
+namespace pcd {
+
+#if 0  // first version of the brick kernel (register staging, one reduction per query); kept for reference only
 template <int G>
-__global__ __launch_bounds__(256) void k_nn_brick(GridParams g, BrickParams b, const float4* __restrict__ sorted,
+__global__ __launch_bounds__(256) void k_nn_brick_v1(GridParams g, BrickParams b, const float4* __restrict__ sorted,
                                                   const uint32_t* __restrict__ cell_start,
                                                   const float4* __restrict__ qf4, const uint32_t* __restrict__ q_order,
                                                   const uint4* __restrict__ items, NnCounters* __restrict__ ctr,
@@ -342,6 +346,7 @@ __global__ __launch_bounds__(256) void k_nn_brick(GridParams g, BrickParams b, c
     atomicAdd(&ctr->brick_groups, st_groups);
   }
 }
+#endif
 
 // --------------------------------------------------------- exact fallback ---
 // scan the point range [s,e): lanes stride over it
@@ -372,6 +377,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
   __shared__ float s_lb[4][kMaxPyrLevels][64];
   __shared__ unsigned long long s_mask[4][kMaxPyrLevels];
   __shared__ int s_node[4][kMaxPyrLevels][3];
+  __shared__ uint32_t s_roff[4][16], s_rsrc[4][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t count = count_ptr ? *count_ptr : count_imm;
   const uint32_t nwaves = gridDim.x * 4;
@@ -417,9 +423,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
         ++lev;
         continue;
       }
-      const bool cand = (m >> lane) & 1ull;
-      const uint64_t sel = wave_min_u64(cand ? (((uint64_t)__float_as_uint(lb) << 32) | (uint32_t)lane) : ~0ull);
-      const int sl = (int)(sel & 63);
+      const int sl = wave_argmin_u32(__float_as_uint(lb), m);  // nearest remaining child (lb >= 0: bit order)
       m &= ~(1ull << sl);
       if (lane == 0) s_mask[wave][lev] = m;
       nx = 4 * s_node[wave][lev][0] + (sl & 3);
@@ -437,14 +441,37 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
             re = cell_start[rowbase + cx1];
           }
         }
-        unsigned long long rows = __ballot(re > rs);
-        while (rows) {
-          const int r = __ffsll((long long)rows) - 1;
-          rows &= rows - 1;
-          const uint32_t a = __shfl(rs, r), bnd = __shfl(re, r);
-          scan_range(sorted, a, bnd, qx, qy, qz, lane_best);
-          st_pts += bnd - a;
+        // The 16 row ranges are scanned as one concatenated range, 256 points per step, with the four
+        // loads of a step issued back to back (clamped indices, no branches around them): one memory
+        // round trip per 256 points instead of one per row.
+        uint32_t Tb;
+        const uint32_t roff = wave_excl_scan_u32(re - rs, Tb);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16) { s_roff[wave][lane] = roff; s_rsrc[wave][lane] = rs; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t base = 0; base < Tb; base += 256) {
+          float4 p[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            uint32_t gi = base + k * 64 + lane;
+            gi = gi < Tb ? gi : Tb - 1;
+            int r = 0;
+#pragma unroll
+            for (int step = 8; step > 0; step >>= 1)
+              if (s_roff[wave][r + step] <= gi) r += step;
+            p[k] = sorted[s_rsrc[wave][r] + (gi - s_roff[wave][r])];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (base + k * 64 + lane < Tb) {
+              const float d = l2_simple3(qx, qy, qz, p[k].x, p[k].y, p[k].z);
+              const uint64_t key = make_key(d, __float_as_uint(p[k].w));
+              lane_best = key < lane_best ? key : lane_best;
+            }
+          }
         }
+        st_pts += Tb;
         best = wave_min_u64(lane_best);
         best_d = __uint_as_float((uint32_t)(best >> 32));
       } else {
@@ -463,7 +490,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
 }
 
 // ------------------------------------------------------------- host driver ---
-static int g_brick_B = 2, g_brick_R = 2, g_collect_stats = 0;
+static int g_brick_B = 2, g_brick_R = 2, g_collect_stats = 0, g_brick_blocks_per_cu = 4;
 
 template <int G>
 static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t* d_keys, hipStream_t s) {
@@ -473,7 +500,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   const BrickParams b = make_bricks(g, B, R);
   PCD_TRY(sc->brick_of.reserve(Q));
   PCD_TRY(sc->rank.reserve(Q));
-  PCD_TRY(sc->q_order.reserve(Q));
+  PCD_TRY(sc->qsorted.reserve(Q));
   PCD_TRY(sc->fb_list.reserve(Q));
   PCD_TRY(sc->brick_cnt.reserve(b.nbricks));
   PCD_TRY(sc->brick_off.reserve(b.nbricks));
@@ -494,15 +521,15 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     PCD_HIP_TRY(rocprim::exclusive_scan(sc->tmp.p, tb, sc->brick_cnt.p, sc->brick_off.p, 0ull, b.nbricks,
                                         rocprim::plus<unsigned long long>(), s));
     hipLaunchKernelGGL(k_brick_emit<G>, dim3(div_up(b.nbricks, 256)), dim3(256), 0, s, sc->brick_cnt.p,
-                       sc->brick_off.p, b.nbricks, sc->items.p, sc->counters.p);
-    hipLaunchKernelGGL(k_brick_scatter, dim3(div_up(Q, 256)), dim3(256), 0, s, sc->brick_of.p, sc->rank.p,
-                       sc->brick_off.p, Q, sc->q_order.p);
+                       sc->brick_off.p, b.nbricks, (uint32_t)b.nb[0], (uint32_t)b.nb[1], sc->items.p, sc->counters.p);
+    hipLaunchKernelGGL(k_brick_scatter, dim3(div_up(Q, 256)), dim3(256), 0, s, sc->qf4.p, sc->brick_of.p, sc->rank.p,
+                       sc->brick_off.p, Q, sc->qsorted.p);
   }
   {
     ScopedKernelTimer t("nn_brick", s);
-    const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(div_up(Q, G), 4) + 1, 256 * 5);
-    hipLaunchKernelGGL(k_nn_brick<G>, dim3(blocks), dim3(256), 0, s, g, b, c->sorted.p, c->cell_start.p, sc->qf4.p,
-                       sc->q_order.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p, g_collect_stats);
+    const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(div_up(Q, G), 4) + 1, 256 * (uint64_t)g_brick_blocks_per_cu);
+    hipLaunchKernelGGL(k_nn_brick<G>, dim3(blocks), dim3(256), 0, s, g, b, c->sorted.p, c->cell_start.p,
+                       sc->qsorted.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p, g_collect_stats);
   }
   {
     ScopedKernelTimer t("nn_fallback", s);

@@ -15,7 +15,7 @@ struct QueryScratch {
   DevBuf<uint64_t> keys;       // host-API result keys
   DevBuf<uint32_t> brick_of;   // per query: brick id or 0xFFFFFFFF
   DevBuf<uint32_t> rank;       // per query: rank inside its brick
-  DevBuf<uint32_t> q_order;    // brick-sorted query ids
+  DevBuf<float4> qsorted;      // brick-sorted query records {x,y,z,bits(query id)}
   DevBuf<unsigned long long> brick_cnt;  // per brick: lo32 = queries, hi32 = items (scan input)
   DevBuf<unsigned long long> brick_off;  // exclusive scan of the above
   DevBuf<uint4> items;         // {first, brick, count, 0}
