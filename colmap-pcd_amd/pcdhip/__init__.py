@@ -203,7 +203,11 @@ class Cloud:
             lib().pcd_cloud_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def __len__(self):
         return int(lib().pcd_cloud_size(self._h))
@@ -348,7 +352,11 @@ class BA:
             lib().pcd_ba_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def set_parameters(self, poses=None, points=None):
         p = None if poses is None else np.ascontiguousarray(poses, np.float64)

@@ -1,0 +1,157 @@
+// lidar_hip.h -- C++ adapters with the reference's own call-site signatures on top of the C ABI.
+//
+// Mirrors (names, argument meaning, error behaviour) of:
+//   colmap::lidar::PointCloudProcess   src/lidar/ply.h:13-40   (Initialize, SearchNearestNeiborByKdtree)
+//   colmap::LidarPoint                 src/lidar/lidar_point.h:10-50
+//   BundleAdjustmentConfig::MatchClosestLidarPoint          src/optim/bundle_adjustment.cc:358-410
+//   the association loops of IncrementalMapper::AdjustGlobalBundleByLidar (sfm/incremental_mapper.cc:1413-1469)
+//   and BundleAdjustmentController::Run (controllers/bundle_adjustment.cc:130-185)
+// Vector types are template parameters: anything indexable with operator()(int) or operator[] works, so
+// Eigen::Vector3d / Eigen::Matrix<double,6,1> drop in unchanged when the reference is built against this.
+// Header-only; link with -lpcdhip.  No CPU fallback: every call fails (returns false) without a gfx950 device.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/pcdhip.h"
+
+namespace colmap_hip {
+
+enum class LidarPointType { Proj, Icp, IcpGround };  // lidar/lidar_point.h:9
+
+// value type recorded per associated 3D point (lidar/lidar_point.h:10-50)
+struct LidarPoint {
+  LidarPointType type = LidarPointType::Icp;
+  std::array<double, 3> xyz{};
+  std::array<double, 4> abcd{};     // after Normalize(): unit normal + d
+  std::array<uint8_t, 3> color{};   // GUI colour chosen at the call site
+  double dist = 0.0;                // SetDist (point-to-point distance on the KD-tree paths)
+  double angle = 0.0;               // SetAngle
+  LidarPointType Type() const { return type; }
+  const std::array<double, 3>& LidarXYZ() const { return xyz; }
+  const std::array<double, 4>& LidarABCD() const { return abcd; }
+  double Dist() const { return dist; }
+  double Angle() const { return angle; }
+};
+
+namespace lidar {
+
+template <typename V>
+inline double vget(const V& v, int i) { return v(i); }
+template <typename T, size_t N>
+inline double vget(const std::array<T, N>& v, int i) { return v[i]; }
+template <typename V>
+inline void vset(V& v, int i, double x) { v(i) = x; }
+template <typename T, size_t N>
+inline void vset(std::array<T, N>& v, int i, double x) { v[i] = x; }
+
+// Replaces lidar::PointCloudProcess for the KD-tree side (the depth-projection side, pcd_proj_, is untouched).
+class PointCloudProcess {
+ public:
+  explicit PointCloudProcess(const std::string& path = "", int device = 0) : path_(path), device_(device) {}
+  ~PointCloudProcess() { pcd_cloud_destroy(cloud_); }
+  PointCloudProcess(const PointCloudProcess&) = delete;
+  PointCloudProcess& operator=(const PointCloudProcess&) = delete;
+
+  // lidar/ply.cc:9-31 after pcl::io::loadPLYFile: rows as stored in the PLY (LiDAR frame, lidarpt::Point
+  // AoS 32 B or two arrays).  Applies the axis swap + NaN filter of ply.cc:33-57 and builds the index.
+  // Returns false on failure like the reference (the caller only prints).
+  bool InitializeFromRawCloud(const float* xyz, const float* nrm, uint64_t n, bool aos32 = false) {
+    pcd_cloud_options o;
+    pcd_cloud_options_default(&o);
+    o.device = device_;
+    o.layout = aos32 ? PCD_LAYOUT_AOS32 : PCD_LAYOUT_XYZ_NRM;
+    o.raw_lidar_frame = 1;
+    pcd_cloud_destroy(cloud_);
+    cloud_ = nullptr;
+    return pcd_cloud_create(xyz, nrm, n, &o, &cloud_) == PCD_OK;
+  }
+
+  // lidar/ply.h:31, ply.cc:90-107 -- unchanged signature; one query per call (correct, launch-bound)
+  template <typename Vec3, typename Vec6>
+  bool SearchNearestNeiborByKdtree(const Vec3& point_3d, Vec6& l_pt) {
+    const double q[3] = {vget(point_3d, 0), vget(point_3d, 1), vget(point_3d, 2)};
+    double l6[6];
+    uint8_t ok = 0;
+    if (!SearchNearestNeiborBatch(q, 1, l6, &ok) || !ok) return false;
+    for (int k = 0; k < 6; ++k) vset(l_pt, k, l6[k]);   // out-param written only on success
+    return true;
+  }
+
+  // batched form used by the patched loops: l6[i] = (xyz, normal) doubles, ok[i] as the bool above
+  bool SearchNearestNeiborBatch(const double* q_xyz, uint64_t n, double* l6, uint8_t* ok) {
+    if (!cloud_) return false;
+    std::vector<double> xyz(3 * n), abcd(4 * n), dist(n), angle(n);
+    std::vector<uint8_t> type(n);
+    std::vector<uint32_t> idx(n);
+    pcd_assoc_out out{xyz.data(), abcd.data(), type.data(), dist.data(), angle.data(), nullptr, idx.data(), nullptr};
+    const double huge = 1e300;  // gate disabled: ok == SearchNearestNeiborByKdtree's return value
+    if (pcd_associate(cloud_, q_xyz, n, &huge, 1, PCD_GATE_MAPPER_LOCAL, &out) != PCD_OK) return false;
+    if (host_nrm_.empty() && !FetchNormals()) return false;
+    for (uint64_t i = 0; i < n; ++i) {
+      ok[i] = type[i] != PCD_LIDAR_NONE;
+      for (int k = 0; k < 3; ++k) {
+        l6[6 * i + k] = xyz[3 * i + k];
+        l6[6 * i + 3 + k] = ok[i] ? (double)host_nrm_[3 * (size_t)idx[i] + k] : 0.0;
+      }
+    }
+    return true;
+  }
+
+  pcd_cloud* handle() const { return cloud_; }
+  uint64_t size() const { return pcd_cloud_size(cloud_); }
+
+ private:
+  bool FetchNormals() {
+    const uint64_t n = pcd_cloud_size(cloud_);
+    host_nrm_.resize(3 * n);
+    std::vector<float> xyz(3 * n);
+    return pcd_cloud_download(cloud_, xyz.data(), host_nrm_.data()) == PCD_OK;
+  }
+  std::string path_;
+  int device_;
+  pcd_cloud* cloud_ = nullptr;
+  std::vector<float> host_nrm_;
+};
+
+}  // namespace lidar
+
+// The three association loops, batched.  gate_mode selects the call site:
+//   PCD_GATE_MAPPER_LOCAL   BundleAdjustmentConfig::MatchClosestLidarPoint (colour green 0,255,0; dist/angle stored)
+//   PCD_GATE_MAPPER_GLOBAL  IncrementalMapper::AdjustGlobalBundleByLidar   (colour blue 0,0,255)
+//   PCD_GATE_CONTROLLER     BundleAdjustmentController::Run                (colour blue 0,0,255)
+// ground points are yellow (255,255,0) at all three.  Returns point3D_id -> LidarPoint for the points the
+// reference would have passed to AddLidarPoint (rejected / not found points are absent).
+inline bool MatchClosestLidarPoints(lidar::PointCloudProcess& pcp, const std::vector<uint64_t>& point3D_ids,
+                                    const std::vector<double>& xyz /*3 per point*/,
+                                    const std::vector<double>& max_search_range /*1 or n entries*/, int gate_mode,
+                                    std::unordered_map<uint64_t, LidarPoint>* lidar_maps) {
+  const uint64_t n = point3D_ids.size();
+  if (xyz.size() != 3 * n || !pcp.handle()) return false;
+  std::vector<double> lx(3 * n), abcd(4 * n), dist(n), angle(n);
+  std::vector<uint8_t> type(n);
+  pcd_assoc_out out{lx.data(), abcd.data(), type.data(), dist.data(), angle.data(), nullptr, nullptr, nullptr};
+  if (pcd_associate(pcp.handle(), xyz.data(), n, max_search_range.data(), max_search_range.size(), gate_mode, &out) !=
+      PCD_OK)
+    return false;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (type[i] == PCD_LIDAR_NONE) continue;
+    LidarPoint lp;
+    lp.type = type[i] == PCD_LIDAR_ICP_GROUND ? LidarPointType::IcpGround : LidarPointType::Icp;
+    for (int k = 0; k < 3; ++k) lp.xyz[k] = lx[3 * i + k];
+    for (int k = 0; k < 4; ++k) lp.abcd[k] = abcd[4 * i + k];
+    if (lp.type == LidarPointType::IcpGround) lp.color = {255, 255, 0};
+    else if (gate_mode == PCD_GATE_MAPPER_LOCAL) lp.color = {0, 255, 0};
+    else lp.color = {0, 0, 255};
+    lp.dist = dist[i];
+    lp.angle = angle[i];
+    (*lidar_maps)[point3D_ids[i]] = lp;
+  }
+  return true;
+}
+
+}  // namespace colmap_hip

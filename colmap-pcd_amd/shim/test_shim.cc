@@ -1,0 +1,224 @@
+// test_shim.cc -- exercises the reference-signature adapters (lidar_hip.h, ba_problem.h).
+//   ./test_shim            structure tests only (no GPU needed)
+//   ./test_shim --gpu      also the GPU paths (fails if no gfx950 device)
+// Expected values marked [ref] are the reference's own (src/optim/bundle_adjustment_test.cc); the
+// others are derived for this fork's defaults (intrinsics constant, optim/bundle_adjustment.h:79-81).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "ba_problem.h"
+#include "lidar_hip.h"
+
+using namespace colmap_hip;
+
+static int g_fail = 0;
+#define CHECK_EQ(a, b)                                                                         \
+  do {                                                                                         \
+    auto _a = (a); auto _b = (b);                                                              \
+    if (!(_a == _b)) { std::printf("FAIL %s:%d: %s == %s (%g vs %g)\n", __FILE__, __LINE__, #a, #b, (double)_a, (double)_b); ++g_fail; } \
+  } while (0)
+#define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); ++g_fail; } } while (0)
+
+// shape of bundle_adjustment_test.cc:123-184 GenerateReconstruction: every image observes every point,
+// SIMPLE_RADIAL f = 1200, 1000 x 1000, identity rotation, t = (U(-1,1), U(-1,1), 10), +-2 px noise
+static void GenerateReconstruction(size_t num_images, size_t num_points, Reconstruction* rec) {
+  std::mt19937 rng(0);
+  std::uniform_real_distribution<double> u(-1.0, 1.0), px(-2.0, 2.0);
+  for (point3D_t p = 1; p <= num_points; ++p) {
+    Point3D pt;
+    for (double& c : pt.xyz) c = u(rng);
+    rec->points3D[p] = pt;
+  }
+  for (image_t i = 0; i < num_images; ++i) {
+    Camera cam;
+    cam.model_id = PCD_CAM_SIMPLE_RADIAL;
+    cam.params = {1200.0, 500.0, 500.0, 0.0};
+    rec->cameras[i] = cam;
+    Image im;
+    im.camera_id = i;
+    im.tvec[0] = u(rng); im.tvec[1] = u(rng); im.tvec[2] = 10;
+    for (point3D_t p = 1; p <= num_points; ++p) {
+      const Point3D& pt = rec->points3D[p];
+      const double X = pt.xyz[0] + im.tvec[0], Y = pt.xyz[1] + im.tvec[1], Z = pt.xyz[2] + im.tvec[2];
+      Point2D p2;
+      p2.xy[0] = 1200.0 * X / Z + 500.0 + px(rng);
+      p2.xy[1] = 1200.0 * Y / Z + 500.0 + px(rng);
+      p2.point3D_id = p;
+      im.points2D.push_back(p2);
+      rec->points3D[p].track.push_back({i, (point2D_t)(p - 1)});
+    }
+    rec->images[i] = im;
+  }
+}
+
+static void DeleteObservation(Reconstruction* rec, image_t image_id, point2D_t idx) {
+  Point2D& p2 = rec->images[image_id].points2D[idx];
+  auto& tr = rec->points3D[p2.point3D_id].track;
+  tr.erase(std::remove_if(tr.begin(), tr.end(), [&](const TrackElement& t) { return t.image_id == image_id && t.point2D_idx == idx; }), tr.end());
+  p2.point3D_id = kInvalidPoint3DId;
+}
+
+static void TestConfigNumObservations() {   // [ref] bundle_adjustment_test.cc:186-210
+  Reconstruction rec;
+  GenerateReconstruction(4, 100, &rec);
+  BundleAdjustmentConfig config;
+  config.AddImage(0);
+  config.AddImage(1);
+  CHECK_EQ(config.NumResiduals(rec), 400u);
+  config.AddVariablePoint(1);
+  CHECK_EQ(config.NumResiduals(rec), 404u);
+  config.AddConstantPoint(2);
+  CHECK_EQ(config.NumResiduals(rec), 408u);
+  config.AddImage(2);
+  CHECK_EQ(config.NumResiduals(rec), 604u);
+  config.AddImage(3);
+  CHECK_EQ(config.NumResiduals(rec), 800u);
+}
+
+static void TestTwoView() {   // bundle_adjustment_test.cc:212-238: [ref] 400 residuals; 309 params = 305 + 4 camera
+  Reconstruction rec;
+  GenerateReconstruction(2, 100, &rec);
+  BundleAdjustmentConfig config;
+  config.AddImage(0); config.AddImage(1);
+  config.SetConstantPose(0);
+  config.SetConstantTvec(1, {0});
+  BundleAdjusterHip ba(BundleAdjustmentOptions(), config);
+  ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
+  CHECK_EQ(ba.NumResiduals(), 400u);
+  CHECK_EQ(ba.NumEffectiveParameters(), 305u);   // 100*3 points + 3 (quaternion tangent) + 2 (tvec y,z)
+  CHECK_EQ(ba.NumConstantPoints(), 0u);
+}
+
+static void TestPartiallyContainedTracks() {   // bundle_adjustment_test.cc:282-323
+  Reconstruction rec;
+  GenerateReconstruction(3, 100, &rec);
+  const point3D_t variable_point = rec.images[2].points2D[0].point3D_id;
+  DeleteObservation(&rec, 2, 0);
+  BundleAdjustmentConfig config;
+  config.AddImage(0); config.AddImage(1);
+  config.SetConstantPose(0); config.SetConstantPose(1);
+  BundleAdjusterHip ba(BundleAdjustmentOptions(), config);
+  ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
+  CHECK_EQ(ba.NumResiduals(), 400u);            // [ref] 400
+  CHECK_EQ(ba.NumConstantPoints(), 99u);        // every track that also lives in image 2 is held constant (:1107-1131)
+  CHECK_EQ(ba.NumEffectiveParameters(), 3u);    // [ref] 7 = 3 + 4 camera parameters
+  for (size_t i = 0; i < ba.point_ids_.size(); ++i) CHECK((ba.point_ids_[i] == variable_point) == (ba.point_const_[i] == 0));
+}
+
+static void TestForceToOptimizePoint() {   // bundle_adjustment_test.cc:325-380
+  Reconstruction rec;
+  GenerateReconstruction(3, 100, &rec);
+  const point3D_t add_variable = rec.images[2].points2D[1].point3D_id;
+  const point3D_t add_constant = rec.images[2].points2D[2].point3D_id;
+  DeleteObservation(&rec, 2, 0);
+  BundleAdjustmentConfig config;
+  config.AddImage(0); config.AddImage(1);
+  config.SetConstantPose(0); config.SetConstantPose(1);
+  config.AddVariablePoint(add_variable);
+  config.AddConstantPoint(add_constant);
+  BundleAdjusterHip ba(BundleAdjustmentOptions(), config);
+  ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
+  // un-reduced: 400 + 2 (variable point seen from image 2) + 2 (constant point seen from image 2);
+  // [ref] 402 is Ceres' *reduced* count, which drops the all-constant block of the constant point
+  CHECK_EQ(ba.NumResiduals(), 404u);
+  CHECK_EQ(ba.NumEffectiveParameters(), 6u);    // [ref] 10 = 6 + 4 camera parameters
+  CHECK_EQ(ba.NumConstantPoints(), 98u);
+}
+
+static void TestLidarBlocks() {   // optim/bundle_adjustment.cc:993-1040 weights / NaN guard, :601-682 phrases
+  Reconstruction rec;
+  GenerateReconstruction(2, 10, &rec);
+  BundleAdjustmentConfig config;
+  config.AddImage(0); config.AddImage(1);
+  for (point3D_t p = 1; p <= 10; ++p) config.AddVariablePoint(p);
+  LidarPoint a; a.type = LidarPointType::Icp; a.abcd = {0, 1, 0, -0.5};
+  LidarPoint b; b.type = LidarPointType::IcpGround; b.abcd = {0, 1, 0, -0.5};
+  LidarPoint c; c.type = LidarPointType::Proj; c.abcd = {0, 1, 0, -0.5};
+  LidarPoint d; d.type = LidarPointType::Icp; d.abcd = {0, NAN, 0, -0.5};
+  config.AddLidarPoint(1, a); config.AddLidarPoint(2, b); config.AddLidarPoint(3, c); config.AddLidarPoint(4, d);
+  BundleAdjusterHip ba(BundleAdjustmentOptions(), config);
+  ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::WholeMap);
+  CHECK_EQ(ba.lidar_point_.size(), 3u);         // NaN plane dropped
+  CHECK_EQ(ba.NumResiduals(), 40u + 3u);
+  CHECK_EQ(ba.lidar_w_[0], 100.0); CHECK_EQ(ba.lidar_w_[1], 1000.0); CHECK_EQ(ba.lidar_w_[2], 1.0);
+  BundleAdjustmentOptions off; off.if_add_lidar_constraint = false;
+  BundleAdjusterHip ba2(off, config);
+  ba2.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::Local);
+  CHECK_EQ(ba2.lidar_point_.size(), 0u);
+  // Global phrase: only points flagged IfInSphere enter (AddImageInSphereToProblem :734)
+  for (point3D_t p = 1; p <= 5; ++p) rec.points3D[p].if_in_sphere = true;
+  BundleAdjusterHip ba3(BundleAdjustmentOptions(), config);
+  ba3.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::Global);
+  CHECK_EQ(ba3.obs_image_.size(), 10u);
+}
+
+static int TestGpu() {
+  if (pcd_device_count() < 1) { std::printf("FAIL: --gpu given but no gfx950 device\n"); return 1; }
+  // cloud: plane y = 1 (visual frame) on a 5 cm lattice with normal (0,1,0), given in the raw LiDAR frame
+  std::vector<float> xyz, nrm;
+  for (int i = 0; i < 200; ++i)
+    for (int j = 0; j < 200; ++j) {
+      const float vx = 0.05f * i, vy = 1.0f, vz = 0.05f * j;           // visual
+      xyz.insert(xyz.end(), {vz, -vx, -vy});                           // raw = (z', -x', -y')
+      nrm.insert(nrm.end(), {0.f, 0.f, -1.f});                         // visual normal (0,1,0)
+    }
+  lidar::PointCloudProcess pcp;
+  CHECK(pcp.InitializeFromRawCloud(xyz.data(), nrm.data(), xyz.size() / 3));
+  CHECK_EQ(pcp.size(), 40000u);
+  std::array<double, 3> q = {2.51, 1.3, 4.02};
+  std::array<double, 6> l6{};
+  CHECK(pcp.SearchNearestNeiborByKdtree(q, l6));
+  CHECK(std::fabs(l6[0] - 2.5) < 1e-6 && std::fabs(l6[1] - 1.0) < 1e-6 && std::fabs(l6[2] - 4.0) < 1e-6);
+  CHECK(l6[3] == 0.0 && l6[4] == 1.0 && l6[5] == 0.0);
+  std::array<double, 3> bad = {NAN, 0, 0};
+  std::array<double, 6> keep = {9, 9, 9, 9, 9, 9};
+  CHECK(!pcp.SearchNearestNeiborByKdtree(bad, keep));
+  CHECK(keep[0] == 9);                                                // out-param untouched on failure
+  // batched MatchClosestLidarPoint: ground plane -> IcpGround, gate at 0.25 m rejects the far one
+  std::vector<uint64_t> ids = {7, 8, 9};
+  std::vector<double> pts = {2.51, 1.3, 4.02, 5.0, 1.2, 5.0, 3.0, 0.9, 3.0};
+  std::unordered_map<uint64_t, LidarPoint> maps;
+  CHECK(MatchClosestLidarPoints(pcp, ids, pts, {0.25}, PCD_GATE_MAPPER_LOCAL, &maps));
+  CHECK_EQ(maps.size(), 2u);
+  CHECK(maps.count(7) == 0 && maps.count(8) == 1 && maps.count(9) == 1);
+  CHECK(maps[8].type == LidarPointType::IcpGround && maps[8].color[0] == 255 && maps[8].color[2] == 0);
+  CHECK(std::fabs(maps[8].abcd[1] - 1.0) < 1e-12 && std::fabs(maps[8].abcd[3] + 1.0) < 1e-6);
+  CHECK(std::fabs(maps[8].dist - 0.2) < 1e-6);
+  // BA evaluator built from the mirrored assembly
+  Reconstruction rec;
+  GenerateReconstruction(3, 50, &rec);
+  BundleAdjustmentConfig config;
+  for (image_t i = 0; i < 3; ++i) config.AddImage(i);
+  config.SetConstantPose(0);
+  for (point3D_t p = 1; p <= 50; ++p) config.AddVariablePoint(p);
+  LidarPoint lp; lp.type = LidarPointType::Icp; lp.abcd = {0, 0, 1, 0.25};
+  config.AddLidarPoint(3, lp);
+  BundleAdjusterHip ba(BundleAdjustmentOptions(), config);
+  ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::WholeMap);
+  CHECK(ba.Create(0));
+  std::vector<double> res(ba.NumResiduals());
+  double cost = 0;
+  pcd_ba_out out{};
+  out.cost = &cost; out.residuals = res.data();
+  CHECK_EQ((int)pcd_ba_evaluate(ba.handle(), &out), (int)PCD_OK);
+  double s = 0;
+  for (double r : res) s += r * r;
+  CHECK(std::fabs(cost - 0.5 * s) <= 1e-9 * cost);
+  CHECK(cost > 0 && cost < 300 * 8.0 + 1e4);   // +-2 px noise on 300 observations + one lidar term
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  TestConfigNumObservations();
+  TestTwoView();
+  TestPartiallyContainedTracks();
+  TestForceToOptimizePoint();
+  TestLidarBlocks();
+  if (argc > 1 && std::strcmp(argv[1], "--gpu") == 0) g_fail += TestGpu();
+  std::printf(g_fail ? "%d FAILED\n" : "ALL OK\n", g_fail);
+  return g_fail ? 1 : 0;
+}
