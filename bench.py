@@ -49,9 +49,10 @@ def parse():
     ap.add_argument("--cams", type=int, default=1000)
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-queries", type=int, default=150_000)
-    ap.add_argument("--cpu-sample-points", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=1_000_000)   # ~2.5 s of one core
+    ap.add_argument("--cpu-sample-points", type=int, default=600_000)      # ~10 s of one core
     ap.add_argument("--no-cloud-sharded", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path)")
     return ap.parse_args()
 
 
@@ -91,9 +92,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal on a 1-GPU box: PCD_BENCH_FORCE_DEVICE=0 puts every rank on that device (use --backend gloo)
+    if os.environ.get("PCD_BENCH_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["PCD_BENCH_FORCE_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream().cuda_stream
@@ -193,9 +200,9 @@ def main():
         shard.close()
 
     if rank == 0:
-        per = {k: ms / n for k, (n, ms) in prof.items()}
-        nn_ms = sum(v for k, v in per.items() if k.startswith("nn_")) + per.get("associate", 0.0)
-        ba_ms = sum(v for k, v in per.items() if k.startswith("ba_"))
+        per = {k: ms / n for k, (n, ms) in prof.items()}                       # average per launch
+        nn_ms = sum(ms for k, (n, ms) in prof.items() if k.startswith("nn_") or k == "associate") / a.steps
+        ba_ms = sum(ms for k, (n, ms) in prof.items() if k.startswith("ba_")) / a.steps   # per step (both passes)
         brick_ms = per.get("nn_brick", float("nan"))
         staged = st["staged_points"] - 0
         alg_bytes = staged * REC_BYTES + PER_QUERY_BYTES * Q

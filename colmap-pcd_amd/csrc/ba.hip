@@ -7,17 +7,21 @@
 // correction (optim/bundle_adjustment.cc:53-68) and the manifold projection
 // (base/cost_functions.h:610-627), then J^T J / J^T r block accumulation.
 //
-// Kernels (all fp64, HBM-bound: ~300 flop per ~60-200 B per observation):
-//   k_ba_points  thread = 3D point (track): walks the point's observations and LiDAR terms,
-//                accumulates its 3x3 block, gradient and the cost.  No atomics: point blocks are
-//                complete inside one thread, the cost goes through a fixed-order two-stage sum.
-//   k_ba_images  workgroup = image: its observations (CSR list) are strided over 256 lanes, each
-//                lane recomputes the 2x6 pose-tangent Jacobian and accumulates 21 + 6 unique
-//                entries; block reduction in a fixed order -> deterministic 6x6 block + gradient.
+// Kernels (all fp64, memory/latency-bound: ~300 flop per ~60-200 B per observation):
+//   k_ba_points  thread = 3D point (track).  Tracks are processed in order of track length and their
+//                observations are stored in a sliced-ELL layout (64 tracks per slice, observation j of
+//                lane l at slice_base + 64 j + l): the lanes of a wavefront run the same number of
+//                iterations and every load instruction reads 64 consecutive records.  Accumulates the
+//                point's 3x3 block, gradient and the cost.  No atomics: point blocks are complete inside
+//                one thread, the cost goes through a fixed-order two-stage sum.
+//   k_ba_images  workgroup = image; its observations are stored image-major (contiguous), strided over
+//                256 lanes; each lane recomputes the 2x6 pose-tangent Jacobian and accumulates 21 + 6
+//                unique entries; fixed-order block reduction -> deterministic 6x6 block + gradient.
 //   k_ba_raw     thread = observation / LiDAR term: the raw ambient blocks exactly as
 //                CostFunction::Evaluate returns them (for the Ceres EvaluationCallback adapter).
-// Jacobians are recomputed in each kernel instead of being staged through HBM: 160 B/obs of
-// Jacobian traffic would cost more than the ~300 flops.
+// Jacobians are recomputed in each kernel instead of being staged through HBM (160 B/obs of traffic
+// would cost more than the ~300 flops).  MODEL >= 0 compiles one camera model in (all cameras of the
+// problem share it -- the usual case); MODEL = -1 switches per observation.
 #include <algorithm>
 #include <numeric>
 
@@ -33,47 +37,61 @@ struct BaDev {
   const double* points; const uint8_t* point_const;
   const int* obs_image; const int* obs_point; const double* obs_xy;
   const int* lidar_point; const double* lidar_abcd; const double* lidar_w;
-  // CSR
-  const uint32_t* pt_obs_start; const uint32_t* pt_obs_list;
+  // per-track (sliced ELL, length-sorted) and per-image (contiguous) copies of the observations
+  const int* pt_order;            // [nslices*64]  thread -> point id (-1 = padding)
+  const uint32_t* slice_start;    // [nslices+1]   first slot of each 64-track slice
+  const int* sell_img;            // [nslots]      image of the observation, -1 = padding
+  const double* sell_xy;          // [nslots][2]
   const uint32_t* pt_lidar_start; const uint32_t* pt_lidar_list;
-  const uint32_t* img_obs_start; const uint32_t* img_obs_list;
-  int I, P; uint64_t O, L;
+  const uint32_t* img_obs_start;  // [I+1]
+  const int* img_pt;              // [O] point of the e-th observation of the image-major order
+  const double* img_xy;           // [O][2]
+  int I, P, nslices; uint64_t O, L;
   int loss_type; double loss_scale;
 };
 
-__device__ __forceinline__ void load_obs_block(const BaDev& d, uint32_t o, ReprojBlock& b, int& im, int& pt,
-                                               double q[4]) {
-  im = d.obs_image[o];
-  pt = d.obs_point[o];
+template <int MODEL>
+__device__ __forceinline__ void eval_block(const BaDev& d, int im, const double X[3], double ox, double oy,
+                                           ReprojBlock& b, double q[4]) {
   const double* pose = d.poses + 7 * (size_t)im;
-  double t[3], X[3];
+  double t[3];
 #pragma unroll
   for (int k = 0; k < 4; ++k) q[k] = pose[k];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { t[k] = pose[4 + k]; X[k] = d.points[3 * (size_t)pt + k]; }
+  for (int k = 0; k < 3; ++k) t[k] = pose[4 + k];
   const int cm = d.image_cam[im];
-  reproj_eval(d.cam_model[cm], d.cam_params + d.cam_off[cm], q, t, X, d.obs_xy[2 * (size_t)o],
-              d.obs_xy[2 * (size_t)o + 1], b);
+  const int model = MODEL >= 0 ? MODEL : d.cam_model[cm];
+  reproj_eval(model, d.cam_params + d.cam_off[cm], q, t, X, ox, oy, b);
 }
 
 // ------------------------------------------------------------- points ------
+// BLOCKS = false: residual-only pass (cost), what Ceres asks for when it evaluates a trial step
+template <int MODEL, bool BLOCKS>
 __global__ __launch_bounds__(256) void k_ba_points(BaDev d, double* __restrict__ Hpt, double* __restrict__ gpt,
                                                    double* __restrict__ cost_partial) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int slice = t >> 6, lane = threadIdx.x & 63;
   double cost = 0.0;
-  if (p < d.P) {
+  if (slice < d.nslices) {
+    const int p = d.pt_order[t];
+    const uint32_t s0 = d.slice_start[slice], s1 = d.slice_start[slice + 1];
     double H[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-    const bool cpt = d.point_const && d.point_const[p];
-    for (uint32_t e = d.pt_obs_start[p]; e < d.pt_obs_start[p + 1]; ++e) {
-      const uint32_t o = d.pt_obs_list[e];
+    double X[3] = {0, 0, 0};
+    bool cpt = true;
+    if (p >= 0) {
+      X[0] = d.points[3 * (size_t)p]; X[1] = d.points[3 * (size_t)p + 1]; X[2] = d.points[3 * (size_t)p + 2];
+      cpt = d.point_const && d.point_const[p];
+    }
+    for (uint32_t s = s0 + lane; s < s1; s += 64) {
+      const int im = d.sell_img[s];
+      if (im < 0) continue;  // padding of a shorter track
       ReprojBlock b;
-      int im, pt;
       double q[4];
-      load_obs_block(d, o, b, im, pt, q);
+      eval_block<MODEL>(d, im, X, d.sell_xy[2 * (size_t)s], d.sell_xy[2 * (size_t)s + 1], b, q);
       double rho0, rho1;
       loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
       cost += 0.5 * rho0;
-      if (!cpt) {
+      if (BLOCKS && !cpt) {
         const double sr = sqrt(rho1);
         double J[6];
 #pragma unroll
@@ -87,30 +105,31 @@ __global__ __launch_bounds__(256) void k_ba_points(BaDev d, double* __restrict__
         g[0] += J[0] * r0 + J[3] * r1; g[1] += J[1] * r0 + J[4] * r1; g[2] += J[2] * r0 + J[5] * r1;
       }
     }
-    const double X[3] = {d.points[3 * (size_t)p], d.points[3 * (size_t)p + 1], d.points[3 * (size_t)p + 2]};
-    for (uint32_t e = d.pt_lidar_start[p]; e < d.pt_lidar_start[p + 1]; ++e) {
-      const uint32_t l = d.pt_lidar_list[e];
-      const double abcd[4] = {d.lidar_abcd[4 * (size_t)l], d.lidar_abcd[4 * (size_t)l + 1],
-                              d.lidar_abcd[4 * (size_t)l + 2], d.lidar_abcd[4 * (size_t)l + 3]};
-      double r, J[3];
-      lidar_eval(X, abcd, d.lidar_w[l], 0, r, J);
-      double rho0, rho1;
-      loss_eval(d.loss_type, d.loss_scale, r * r, rho0, rho1);
-      cost += 0.5 * rho0;
-      if (!cpt) {
-        const double sr = sqrt(rho1);
-        const double rc = sr * r;
-        J[0] *= sr; J[1] *= sr; J[2] *= sr;
-        H[0] += J[0] * J[0]; H[1] += J[0] * J[1]; H[2] += J[0] * J[2];
-        H[3] += J[1] * J[1]; H[4] += J[1] * J[2]; H[5] += J[2] * J[2];
-        g[0] += J[0] * rc; g[1] += J[1] * rc; g[2] += J[2] * rc;
+    if (p >= 0) {
+      for (uint32_t e = d.pt_lidar_start[p]; e < d.pt_lidar_start[p + 1]; ++e) {
+        const uint32_t l = d.pt_lidar_list[e];
+        const double abcd[4] = {d.lidar_abcd[4 * (size_t)l], d.lidar_abcd[4 * (size_t)l + 1],
+                                d.lidar_abcd[4 * (size_t)l + 2], d.lidar_abcd[4 * (size_t)l + 3]};
+        double r, J[3];
+        lidar_eval(X, abcd, d.lidar_w[l], 0, r, J);
+        double rho0, rho1;
+        loss_eval(d.loss_type, d.loss_scale, r * r, rho0, rho1);
+        cost += 0.5 * rho0;
+        if (BLOCKS && !cpt) {
+          const double sr = sqrt(rho1);
+          const double rc = sr * r;
+          J[0] *= sr; J[1] *= sr; J[2] *= sr;
+          H[0] += J[0] * J[0]; H[1] += J[0] * J[1]; H[2] += J[0] * J[2];
+          H[3] += J[1] * J[1]; H[4] += J[1] * J[2]; H[5] += J[2] * J[2];
+          g[0] += J[0] * rc; g[1] += J[1] * rc; g[2] += J[2] * rc;
+        }
       }
+      if (BLOCKS && Hpt) {
+        double* h = Hpt + 9 * (size_t)p;
+        h[0] = H[0]; h[1] = H[1]; h[2] = H[2]; h[3] = H[1]; h[4] = H[3]; h[5] = H[4]; h[6] = H[2]; h[7] = H[4]; h[8] = H[5];
+      }
+      if (BLOCKS && gpt) { gpt[3 * (size_t)p] = g[0]; gpt[3 * (size_t)p + 1] = g[1]; gpt[3 * (size_t)p + 2] = g[2]; }
     }
-    if (Hpt) {
-      double* h = Hpt + 9 * (size_t)p;
-      h[0] = H[0]; h[1] = H[1]; h[2] = H[2]; h[3] = H[1]; h[4] = H[3]; h[5] = H[4]; h[6] = H[2]; h[7] = H[4]; h[8] = H[5];
-    }
-    if (gpt) { gpt[3 * (size_t)p] = g[0]; gpt[3 * (size_t)p + 1] = g[1]; gpt[3 * (size_t)p + 2] = g[2]; }
   }
   // fixed-order block sum of the cost
   __shared__ double s_c[256];
@@ -123,7 +142,6 @@ __global__ __launch_bounds__(256) void k_ba_points(BaDev d, double* __restrict__
   if (threadIdx.x == 0) cost_partial[blockIdx.x] = s_c[0];
 }
 
-// observations whose point is not listed (cannot happen) need no handling; the final cost sum:
 __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int n, double* __restrict__ out) {
   __shared__ double s_c[256];
   double acc = 0.0;
@@ -138,6 +156,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
 }
 
 // ------------------------------------------------------------- images ------
+template <int MODEL>
 __global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__ Himg, double* __restrict__ gimg) {
   const int im = blockIdx.x;
   const bool cpose = d.image_const_pose && d.image_const_pose[im];
@@ -147,11 +166,11 @@ __global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__
   if (!cpose) {
     const unsigned tmask = d.image_const_tvec ? d.image_const_tvec[im] : 0u;
     for (uint32_t e = d.img_obs_start[im] + threadIdx.x; e < d.img_obs_start[im + 1]; e += 256) {
-      const uint32_t o = d.img_obs_list[e];
+      const int pt = d.img_pt[e];
+      const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
       ReprojBlock b;
-      int im2, pt;
       double q[4];
-      load_obs_block(d, o, b, im2, pt, q);
+      eval_block<MODEL>(d, im, X, d.img_xy[2 * (size_t)e], d.img_xy[2 * (size_t)e + 1], b, q);
       double rho0, rho1;
       loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
       const double sr = sqrt(rho1);
@@ -192,8 +211,7 @@ __global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__
     if (threadIdx.x >= 21) {
       if (gimg) gimg[6 * (size_t)im + (threadIdx.x - 21)] = v;
     } else if (Himg) {
-      // unpack the upper triangle index
-      int a = 0, k = threadIdx.x;
+      int a = 0, k = threadIdx.x;  // unpack the upper-triangle index
       while (k >= 6 - a) { k -= 6 - a; ++a; }
       const int c = a + k;
       Himg[36 * (size_t)im + 6 * a + c] = v;
@@ -203,15 +221,17 @@ __global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__
 }
 
 // ---------------------------------------------------------------- raw ------
+template <int MODEL>
 __global__ __launch_bounds__(256) void k_ba_raw(BaDev d, double* __restrict__ residuals, double* __restrict__ Jq_o,
                                                 double* __restrict__ Jt_o, double* __restrict__ JX_o,
                                                 double* __restrict__ W_o) {
   const uint64_t o = blockIdx.x * (uint64_t)256 + threadIdx.x;
   if (o >= d.O) return;
+  const int im = d.obs_image[o], pt = d.obs_point[o];
+  const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
   ReprojBlock b;
-  int im, pt;
   double q[4];
-  load_obs_block(d, (uint32_t)o, b, im, pt, q);
+  eval_block<MODEL>(d, im, X, d.obs_xy[2 * o], d.obs_xy[2 * o + 1], b, q);
   double Jq[8], Jt[6], JX[6];
   reproj_jacobians(b, Jq, Jt, JX);
   const bool cpose = d.image_const_pose && d.image_const_pose[im];
@@ -256,15 +276,16 @@ using namespace pcd;
 
 struct pcd_ba {
   int device = 0;
-  int C = 0, I = 0, P = 0;
+  int C = 0, I = 0, P = 0, nslices = 0;
   uint64_t O = 0, L = 0;
   int loss_type = 0;
   double loss_scale = 1.0;
-  DevBuf<int> cam_model, cam_off, image_cam, obs_image, obs_point, lidar_point;
-  DevBuf<double> cam_params, poses, points, obs_xy, lidar_abcd, lidar_w;
+  int uniform_model = -1;  // >= 0: every camera has this model
+  DevBuf<int> cam_model, cam_off, image_cam, obs_image, obs_point, lidar_point, pt_order, sell_img, img_pt;
+  DevBuf<double> cam_params, poses, points, obs_xy, lidar_abcd, lidar_w, sell_xy, img_xy;
   DevBuf<uint8_t> image_const_pose, image_const_tvec, point_const;
   bool has_cpose = false, has_ctvec = false, has_cpt = false;
-  DevBuf<uint32_t> pt_obs_start, pt_obs_list, pt_lidar_start, pt_lidar_list, img_obs_start, img_obs_list;
+  DevBuf<uint32_t> slice_start, pt_lidar_start, pt_lidar_list, img_obs_start;
   DevBuf<double> cost_partial, cost;
   // host-API staging
   DevBuf<double> o_res, o_jq, o_jt, o_jx, o_jl, o_himg, o_gimg, o_hpt, o_gpt, o_w;
@@ -277,10 +298,10 @@ struct pcd_ba {
     d.points = points.p; d.point_const = has_cpt ? point_const.p : nullptr;
     d.obs_image = obs_image.p; d.obs_point = obs_point.p; d.obs_xy = obs_xy.p;
     d.lidar_point = lidar_point.p; d.lidar_abcd = lidar_abcd.p; d.lidar_w = lidar_w.p;
-    d.pt_obs_start = pt_obs_start.p; d.pt_obs_list = pt_obs_list.p;
+    d.pt_order = pt_order.p; d.slice_start = slice_start.p; d.sell_img = sell_img.p; d.sell_xy = sell_xy.p;
     d.pt_lidar_start = pt_lidar_start.p; d.pt_lidar_list = pt_lidar_list.p;
-    d.img_obs_start = img_obs_start.p; d.img_obs_list = img_obs_list.p;
-    d.I = I; d.P = P; d.O = O; d.L = L; d.loss_type = loss_type; d.loss_scale = loss_scale;
+    d.img_obs_start = img_obs_start.p; d.img_pt = img_pt.p; d.img_xy = img_xy.p;
+    d.I = I; d.P = P; d.nslices = nslices; d.O = O; d.L = L; d.loss_type = loss_type; d.loss_scale = loss_scale;
     return d;
   }
 };
@@ -303,13 +324,26 @@ static void build_csr(const int32_t* key, uint64_t n, int nkeys, std::vector<uin
   for (uint64_t i = 0; i < n; ++i) list[cur[key[i]]++] = (uint32_t)i;
 }
 
+// kernel dispatch on the (uniform) camera model; the five common models are compiled in
+#define PCD_BA_DISPATCH(MODELVAR, ...)                            \
+  switch (MODELVAR) {                                             \
+    case 0: { constexpr int M = 0; __VA_ARGS__; } break;          \
+    case 1: { constexpr int M = 1; __VA_ARGS__; } break;          \
+    case 2: { constexpr int M = 2; __VA_ARGS__; } break;          \
+    case 3: { constexpr int M = 3; __VA_ARGS__; } break;          \
+    case 4: { constexpr int M = 4; __VA_ARGS__; } break;          \
+    default: { constexpr int M = -1; __VA_ARGS__; } break;        \
+  }
+
 extern "C" {
 
 pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
   PCD_REQUIRE(d && out, "null pointer");
   *out = nullptr;
-  PCD_REQUIRE(d->camera_refine == nullptr, "refining intrinsics is not implemented (reference default: constant)");
-  if (d->camera_refine) return PCD_ERR_UNSUPPORTED;
+  if (d->camera_refine) {
+    set_error("refining intrinsics is not implemented (the reference's default holds them constant)");
+    return PCD_ERR_UNSUPPORTED;
+  }
   PCD_REQUIRE(d->num_cameras > 0 && d->cam_model && d->cam_param_offset && d->cam_params, "cameras");
   PCD_REQUIRE(d->num_images > 0 && d->poses && d->image_camera, "images");
   PCD_REQUIRE(d->num_points > 0 && d->points, "points");
@@ -338,6 +372,9 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
   b->device = d->device;
   b->C = d->num_cameras; b->I = d->num_images; b->P = d->num_points; b->O = d->num_obs; b->L = d->num_lidar;
   b->loss_type = d->loss_type; b->loss_scale = d->loss_scale;
+  b->uniform_model = d->cam_model[0];
+  for (int c = 1; c < d->num_cameras; ++c)
+    if (d->cam_model[c] != b->uniform_model) b->uniform_model = -1;
   auto fail = [&](pcd_status st) { pcd_ba_destroy(b); return st; };
 #define UP(buf, src, n) do { pcd_status _st = upload(b->buf, src, (size_t)(n)); if (_st != PCD_OK) return fail(_st); } while (0)
   UP(cam_model, d->cam_model, b->C); UP(cam_off, d->cam_param_offset, b->C); UP(cam_params, d->cam_params, d->cam_params_len);
@@ -348,15 +385,65 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
   if (d->image_const_pose) { b->has_cpose = true; UP(image_const_pose, d->image_const_pose, b->I); }
   if (d->image_const_tvec) { b->has_ctvec = true; UP(image_const_tvec, d->image_const_tvec, b->I); }
   if (d->point_const) { b->has_cpt = true; UP(point_const, d->point_const, b->P); }
+
   std::vector<uint32_t> st, li;
+  // ---- per-track sliced ELL in order of track length ----
   build_csr(d->obs_point, b->O, b->P, st, li);
-  UP(pt_obs_start, st.data(), st.size()); UP(pt_obs_list, li.data(), li.size());
+  {
+    std::vector<int> order(b->P);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return st[a + 1] - st[a] < st[c + 1] - st[c]; });
+    const int nslices = (b->P + 63) / 64;
+    b->nslices = nslices;
+    order.resize((size_t)nslices * 64, -1);
+    std::vector<uint32_t> slice_start(nslices + 1, 0);
+    for (int s = 0; s < nslices; ++s) {
+      uint32_t mx = 0;
+      for (int l = 0; l < 64; ++l) {
+        const int p = order[(size_t)s * 64 + l];
+        if (p >= 0) mx = std::max(mx, st[p + 1] - st[p]);
+      }
+      slice_start[s + 1] = slice_start[s] + mx * 64;
+    }
+    const size_t nslots = slice_start[nslices];
+    std::vector<int> sell_img(std::max<size_t>(nslots, 1), -1);
+    std::vector<double> sell_xy(std::max<size_t>(2 * nslots, 2), 0.0);
+    for (int s = 0; s < nslices; ++s)
+      for (int l = 0; l < 64; ++l) {
+        const int p = order[(size_t)s * 64 + l];
+        if (p < 0) continue;
+        for (uint32_t j = 0; j < st[p + 1] - st[p]; ++j) {
+          const uint32_t o = li[st[p] + j];
+          const size_t slot = (size_t)slice_start[s] + 64 * (size_t)j + l;
+          sell_img[slot] = d->obs_image[o];
+          sell_xy[2 * slot] = d->obs_xy[2 * (size_t)o];
+          sell_xy[2 * slot + 1] = d->obs_xy[2 * (size_t)o + 1];
+        }
+      }
+    UP(pt_order, order.data(), order.size());
+    UP(slice_start, slice_start.data(), slice_start.size());
+    UP(sell_img, sell_img.data(), sell_img.size());
+    UP(sell_xy, sell_xy.data(), sell_xy.size());
+  }
   build_csr(d->lidar_point, b->L, b->P, st, li);
   UP(pt_lidar_start, st.data(), st.size()); UP(pt_lidar_list, li.data(), li.size());
+  // ---- per-image contiguous copies ----
   build_csr(d->obs_image, b->O, b->I, st, li);
-  UP(img_obs_start, st.data(), st.size()); UP(img_obs_list, li.data(), li.size());
+  {
+    std::vector<int> img_pt(std::max<size_t>(b->O, 1));
+    std::vector<double> img_xy(std::max<size_t>(2 * b->O, 2));
+    for (uint64_t e = 0; e < b->O; ++e) {
+      const uint32_t o = li[e];
+      img_pt[e] = d->obs_point[o];
+      img_xy[2 * e] = d->obs_xy[2 * (size_t)o];
+      img_xy[2 * e + 1] = d->obs_xy[2 * (size_t)o + 1];
+    }
+    UP(img_obs_start, st.data(), st.size());
+    UP(img_pt, img_pt.data(), img_pt.size());
+    UP(img_xy, img_xy.data(), img_xy.size());
+  }
 #undef UP
-  pcd_status s1 = b->cost_partial.reserve(div_up(b->P, 256));
+  pcd_status s1 = b->cost_partial.reserve(div_up((size_t)b->nslices * 64, 256));
   if (s1 != PCD_OK) return fail(s1);
   if ((s1 = b->cost.reserve(1)) != PCD_OK) return fail(s1);
   *out = b;
@@ -389,22 +476,30 @@ pcd_status pcd_ba_evaluate_device(pcd_ba* b, const pcd_ba_out* o, void* stream) 
   PCD_HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
   const BaDev d = b->dev();
+  const int model = b->uniform_model;
   if (o->cost || o->H_pt || o->g_pt) {
-    const unsigned blocks = div_up(b->P, 256);
+    const unsigned blocks = div_up((size_t)b->nslices * 64, 256);
+    const bool want_blocks = o->H_pt || o->g_pt;
     {
-      ScopedKernelTimer t("ba_points", s);
-      hipLaunchKernelGGL(k_ba_points, dim3(blocks), dim3(256), 0, s, d, o->H_pt, o->g_pt, b->cost_partial.p);
+      ScopedKernelTimer t(want_blocks ? "ba_points" : "ba_points_cost", s);
+      if (want_blocks) {
+        PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_points<M, true>), dim3(blocks), dim3(256), 0, s, d, o->H_pt,
+                                                   o->g_pt, b->cost_partial.p));
+      } else {
+        PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_points<M, false>), dim3(blocks), dim3(256), 0, s, d,
+                                                   (double*)nullptr, (double*)nullptr, b->cost_partial.p));
+      }
     }
     if (o->cost) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, b->cost_partial.p, (int)blocks, o->cost);
   }
   if (o->H_img || o->g_img) {
     ScopedKernelTimer t("ba_images", s);
-    hipLaunchKernelGGL(k_ba_images, dim3(b->I), dim3(256), 0, s, d, o->H_img, o->g_img);
+    PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_images<M>), dim3(b->I), dim3(256), 0, s, d, o->H_img, o->g_img));
   }
   if ((o->residuals || o->jac_q || o->jac_t || o->jac_X || o->W) && b->O) {
     ScopedKernelTimer t("ba_raw", s);
-    hipLaunchKernelGGL(k_ba_raw, dim3(div_up(b->O, 256)), dim3(256), 0, s, d, o->residuals, o->jac_q, o->jac_t,
-                       o->jac_X, o->W);
+    PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_raw<M>), dim3(div_up(b->O, 256)), dim3(256), 0, s, d, o->residuals,
+                                               o->jac_q, o->jac_t, o->jac_X, o->W));
   }
   if ((o->residuals || o->jac_lidar) && b->L) {
     ScopedKernelTimer t("ba_lidar_raw", s);

@@ -18,7 +18,17 @@
 
 namespace pcd {
 
-constexpr int kTile = 256;  // points per LDS tile buffer (4 KiB); two buffers per wavefront
+// build-time knobs (tools/nn_tune.sh sweeps them): points per LDS tile buffer (two buffers per
+// wavefront) and the wavefronts per SIMD the register allocator must leave room for
+#ifndef PCD_KTILE
+#define PCD_KTILE 256
+#endif
+#ifndef PCD_BRICK_MINWAVES
+#define PCD_BRICK_MINWAVES 4
+#endif
+constexpr int kTile = PCD_KTILE;
+static_assert(kTile == 128 || kTile == 192 || kTile == 256, "tile = 2, 3 or 4 DMA instructions");
+constexpr int kAblateCompare = 0x100, kAblateDma = 0x200, kAblateReduce = 0x400, kAblateFallback = 0x800;
 
 __device__ __forceinline__ void lds_dma16(const float4* gsrc, float4* lds_wave_base) {
   // LDS destination = wave-uniform base + lane * 16 (hardware adds the lane offset)
@@ -69,6 +79,22 @@ __device__ __forceinline__ uint64_t wave_min8_u64(const uint64_t (&v)[8]) {
   return c;
 }
 
+// One staged point against NQ wave-uniform queries: 8 scalar f32 ops (FLANN's ((dx*dx) + dy*dy) + dz*dz,
+// no FMA) + one u64 min of the packed (distance, index) key per query.  The kernel is bound by VALU
+// issue; measured alternatives that did NOT help: packed v_pk_add/mul_f32 for two queries per instruction
+// (1.13 ms vs 1.06 ms: the packed forms issue at half rate), 32-bit lexicographic compares instead of
+// v_cmp_lt_u64 (3 compares + 2 SALU per query), more wavefronts per SIMD (5, 6, 8: within 3 %).
+template <int NQ>
+__device__ __forceinline__ void compare_point(const f32x4 p, const float (&qx)[8], const float (&qy)[8],
+                                              const float (&qz)[8], uint64_t (&best)[8]) {
+  const uint32_t pi = __float_as_uint(p.w);
+#pragma unroll
+  for (int s = 0; s < NQ; ++s) {
+    const float d = l2_simple3(qx[s], qy[s], qz[s], p.x, p.y, p.z);
+    best[s] = min_u64(best[s], make_key(d, pi));
+  }
+}
+
 struct BrickMeta {   // per-group loads issued one group ahead
   float4 q;          // lane < cnt: query (x,y,z, bits(query id))
   uint32_t s, e;     // lane < nrows: point range of the lane's cell row
@@ -112,13 +138,14 @@ __device__ __forceinline__ BrickMeta brick_load_meta(const GridParams& g, const 
 }
 
 template <int G>
-__global__ __launch_bounds__(256) void k_nn_brick(GridParams g, BrickParams b, const float4* __restrict__ sorted,
+__global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams g, BrickParams b, const float4* __restrict__ sorted,
                                                   const uint32_t* __restrict__ cell_start,
                                                   const float4* __restrict__ qsorted,
                                                   const uint4* __restrict__ items, NnCounters* __restrict__ ctr,
                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ fb_list,
-                                                  int collect_stats) {
-  static_assert(kTile == 256, "the asm tile read is written for 4 x 64 records");
+                                                  int flags) {
+  // flags: bit 0 = collect statistics; bits 8.. = timing-only ablations (results are then wrong)
+  const int collect_stats = flags & 1;
   static_assert(G == 8, "the transposed reduction is written for 8 queries per group");
   __shared__ __attribute__((aligned(16))) float4 s_tile[4][2][kTile];
   __shared__ uint32_t s_rowoff[4][kMaxRows];
@@ -158,7 +185,7 @@ __global__ __launch_bounds__(256) void k_nn_brick(GridParams g, BrickParams b, c
 
     // ---- current group ----
     const uint32_t cnt = (uint32_t)item_count(it0);
-    float qx[G], qy[G], qz[G];
+    float qx[G], qy[G], qz[G];   // wave-uniform (SGPRs)
 #pragma unroll
     for (int k = 0; k < G; ++k) {
       const int src = k < (int)cnt ? k : 0;  // empty slots repeat query 0; their results are not written
@@ -194,14 +221,17 @@ __global__ __launch_bounds__(256) void k_nn_brick(GridParams g, BrickParams b, c
 #pragma unroll
           for (int step = 32; step > 0; step >>= 1)
             if (rowoff[r + step] <= gi) r += step;  // largest r with rowoff[r] <= gi (empty rows share offsets)
-          lds_dma16(sorted + (rowsrc[r] + (gi - rowoff[r])), buf + k * 64);
+          if (!(flags & kAblateDma)) lds_dma16(sorted + (rowsrc[r] + (gi - rowoff[r])), buf + k * 64);
         }
       };
       issue_tile(0);
       for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) {
           issue_tile(t + 1);
-          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile t landed, tile t+1 still in flight
+          // tile t landed, the kTile/64 DMAs of tile t+1 still in flight
+          if constexpr (kTile == 256) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else if constexpr (kTile == 192) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -211,43 +241,47 @@ __global__ __launch_bounds__(256) void k_nn_brick(GridParams g, BrickParams b, c
         // s_waitcnt vmcnt(0) (it cannot tell the two buffers apart) and drain tile t+1's DMAs.
         f32x4 p[kTile / 64];
         const uint32_t rd = lds_addr(s_tile[wave][t & 1]) + lane * 16;
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
-                     "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
-                     : "v"(rd)
-                     : "memory");
+        if constexpr (kTile == 256) {
+          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                       "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
+                       "s_waitcnt lgkmcnt(0)"
+                       : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
+                       : "v"(rd)
+                       : "memory");
+        } else if constexpr (kTile == 192) {
+          asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\t"
+                       "ds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2])
+                       : "v"(rd)
+                       : "memory");
+        } else {
+          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(p[0]), "=&v"(p[1])
+                       : "v"(rd)
+                       : "memory");
+        }
         // half-filled groups (cnt <= G/2, wave-uniform) skip the empty query slots
-        if (cnt <= G / 2) {
+        if (flags & kAblateCompare) {
 #pragma unroll
-          for (int k = 0; k < kTile / 64; ++k) {
-            if (k * 64 + lane < tn) {
-              const uint32_t pi = __float_as_uint(p[k].w);
+          for (int k = 0; k < kTile / 64; ++k) asm volatile("" ::"v"(p[k]));
+        } else if (cnt <= G / 4) {
 #pragma unroll
-              for (int qk = 0; qk < G / 2; ++qk) {
-                const float d = l2_simple3(qx[qk], qy[qk], qz[qk], p[k].x, p[k].y, p[k].z);
-                best[qk] = min_u64(best[qk], make_key(d, pi));
-              }
-            }
-          }
+          for (int k = 0; k < kTile / 64; ++k)
+            if (k * 64 + lane < tn) compare_point<G / 4>(p[k], qx, qy, qz, best);
+        } else if (cnt <= G / 2) {
+#pragma unroll
+          for (int k = 0; k < kTile / 64; ++k)
+            if (k * 64 + lane < tn) compare_point<G / 2>(p[k], qx, qy, qz, best);
         } else {
 #pragma unroll
-          for (int k = 0; k < kTile / 64; ++k) {
-            if (k * 64 + lane < tn) {
-              const uint32_t pi = __float_as_uint(p[k].w);
-#pragma unroll
-              for (int qk = 0; qk < G; ++qk) {
-                const float d = l2_simple3(qx[qk], qy[qk], qz[qk], p[k].x, p[k].y, p[k].z);
-                best[qk] = min_u64(best[qk], make_key(d, pi));
-              }
-            }
-          }
+          for (int k = 0; k < kTile / 64; ++k)
+            if (k * 64 + lane < tn) compare_point<G>(p[k], qx, qy, qz, best);
         }
         // (the reads of this buffer have returned -- waited inside the asm block -- before tile t+2's DMAs)
       }
     }
     // ---- one transposed reduction for the 8 queries; lane k fetches result k ----
-    const uint64_t red = wave_min8_u64(best);
+    const uint64_t red = (flags & kAblateReduce) ? best[0] : wave_min8_u64(best);
     // value index v sits in lanes with bits (5,4,3) = v  ->  lane 8*bitrev... v = b5*4 + b4*2 + b3
     const int holder = ((lane & 4) ? 32 : 0) | ((lane & 2) ? 16 : 0) | ((lane & 1) ? 8 : 0);
     const uint64_t mine = ((uint64_t)__shfl((uint32_t)(red >> 32), holder) << 32) | __shfl((uint32_t)red, holder);
@@ -256,7 +290,7 @@ __global__ __launch_bounds__(256) void k_nn_brick(GridParams g, BrickParams b, c
       const uint32_t my_qi = __float_as_uint(m0.q.w);
       const double bound = proven_bound(g, m0.q.x, m0.q.y, m0.q.z, c0, c1);
       const double bd = (double)__uint_as_float((uint32_t)(mine >> 32));
-      unproven = !(bd < bound);
+      unproven = !(bd < bound) && !(flags & kAblateFallback);
       keys[my_qi] = mine;  // final, or the starting bound of the fallback
     }
     const unsigned long long um = __ballot(unproven);

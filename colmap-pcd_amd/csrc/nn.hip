@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
 }
 
 // ------------------------------------------------------------- host driver ---
-static int g_brick_B = 2, g_brick_R = 2, g_collect_stats = 0, g_brick_blocks_per_cu = 4;
+static int g_brick_B = 2, g_brick_R = 2, g_collect_stats = 0, g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
 
 template <int G>
 static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t* d_keys, hipStream_t s) {

@@ -12,7 +12,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)            # colmap-pcd_amd/
-LIB_PATH = os.path.join(_ROOT, "libpcdhip.so")
+LIB_PATH = os.environ.get("PCDHIP_LIB", os.path.join(_ROOT, "libpcdhip.so"))   # override: tuning variants only
 
 PCD_OK, PCD_ERR_INVALID, PCD_ERR_NO_DEVICE, PCD_ERR_HIP, PCD_ERR_OOM, PCD_ERR_UNSUPPORTED = range(6)
 NN_AUTO, NN_BRUTEFORCE, NN_FALLBACK_ONLY = 0, 1, 2

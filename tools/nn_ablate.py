@@ -1,0 +1,33 @@
+"""timing-only ablations of k_nn_brick (results are wrong while a flag is set): python tools/nn_ablate.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "colmap-pcd_amd"))
+import torch  # noqa: E402
+import pcdhip  # noqa: E402
+from pcdhip import synth  # noqa: E402
+
+N, Q = 10_000_000, 1_000_000
+xyz, nrm = synth.cloud_planes(N)
+q = synth.queries(xyz, Q)
+c = pcdhip.Cloud(xyz, nrm, raw_lidar_frame=False)
+dq = torch.from_numpy(q).cuda()
+keys = torch.empty(Q, dtype=torch.int64, device="cuda")
+F = 0x800  # never hand anything to the fallback (keeps the brick kernel's control flow comparable)
+for name, fl in [("full", 0), ("full, no fallback list", F), ("no-compare", F | 0x100), ("no-dma", F | 0x200),
+                 ("no-reduce", F | 0x400), ("no-compare+no-dma", F | 0x300), ("no-compare+no-dma+no-reduce", F | 0x700),
+                 ("full", 0)]:
+    pcdhip.set_nn_tuning(0, -1, fl)
+    for _ in range(3):
+        c.nn_device(dq, Q, keys)
+    torch.cuda.synchronize()
+    pcdhip.profile_enable(True)
+    pcdhip.profile_reset()
+    for _ in range(10):
+        c.nn_device(dq, Q, keys)
+    torch.cuda.synchronize()
+    p = pcdhip.profile_get()
+    pcdhip.profile_enable(False)
+    print("%-30s nn_brick %.3f ms   fallback %.3f ms" % (name, p["nn_brick"][1] / p["nn_brick"][0],
+                                                          p["nn_fallback"][1] / p["nn_fallback"][0]), flush=True)
