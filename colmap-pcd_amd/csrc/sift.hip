@@ -1,0 +1,317 @@
+// sift.hip -- exact brute-force SIFT descriptor matching on the matrix cores.
+//
+// Replaces feature/sift.cc:171-204 (ComputeSiftDistanceMatrix: int32 dot products of uint8 x 128
+// descriptors), :55-107 (FindBestMatchesOneWayBruteForce: best / second best per row, acos + distance
+// and ratio tests) and :109-144 (FindBestMatchesBruteForce: cross check) -- the exact specification that
+// SiftGPU's MultiplyDescriptor / RowMatch / ColMatch kernels (lib/SiftGPU/ProgramCU.cu:1408-1795) and the
+// CPU brute-force matcher implement.  This is the one dense contraction of the path, hence MFMA:
+//
+//   S[i][j] = sum_k a[i][k] b[j][k]   (uint8 inputs, exact int32)
+//           = sum_k (a-128)(b-128) + 128 (sum_k a[i][k] + sum_k b[j][k]) - 128*128*128
+// so the bytes are re-centred to int8 (a ^ 0x80) and fed to v_mfma_i32_32x32x32_i8 (K = 32 per
+// instruction, int32 accumulate: exact), the row-sum correction is added in the epilogue.
+//
+// k_sift_scores: one 128 x 128 score tile per workgroup (4 wavefronts, 64 x 64 each).  Both sets' tiles
+// (128 rows x 128 B) are staged once in LDS (144-B row pitch: conflict-free ds_read_b128 fragments).  The
+// tile is computed TWICE from the same fragments, as A.B^T and as B.A^T: in the MFMA result layout a lane
+// owns one column and 16 rows per 32x32 block, so the best / second-best scan over the *other* set is a
+// register-local loop in both directions (no cross-lane top-2 reductions, no score matrix in memory) --
+// 32 extra MFMAs per wavefront are cheaper than 64 shuffled reductions.  Per tile and direction one
+// (best, second, argbest) triple per descriptor goes to a partial buffer; k_sift_finalize merges the
+// partials in ascending tile order (ties -> first index, as the reference's ascending strict-> scan),
+// applies acos / max_distance / max_ratio; the cross check and the ordered compaction follow.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace pcd {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int kSiftTile = 128;
+constexpr int kSiftPitch = 144;   // bytes per staged descriptor row (128 + 16 pad)
+constexpr int kSiftConst = 128 * 128 * 128;
+
+__global__ void k_sift_rowsum(const uint8_t* __restrict__ d, int n, int* __restrict__ sum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* p = reinterpret_cast<const uint4*>(d + (size_t)i * 128);
+  unsigned s = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const uint4 v = p[c];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += (w[k] & 0xFF) + ((w[k] >> 8) & 0xFF) + ((w[k] >> 16) & 0xFF) + (w[k] >> 24);
+  }
+  sum[i] = (int)s;
+}
+
+// running (best, second, argbest) with the reference's update rule: strictly greater replaces the best
+__device__ __forceinline__ void top2_update(int v, int idx, int& best, int& second, int& arg) {
+  second = max(second, min(v, best));
+  const bool gt = v > best;
+  arg = gt ? idx : arg;
+  best = max(best, v);
+}
+// merge another triple; on equal best the lower index wins (= first in an ascending scan)
+__device__ __forceinline__ void top2_merge(int b2, int s2, int a2, int& best, int& second, int& arg) {
+  const int nsecond = max(max(second, s2), min(best, b2));
+  const bool take = (b2 > best) || (b2 == best && (unsigned)a2 < (unsigned)arg);
+  arg = take ? a2 : arg;
+  best = max(best, b2);
+  second = nsecond;
+}
+
+// part12 [n1][nbx] / part21 [n2][nby] int4 {best, second, arg, 0}
+__global__ __launch_bounds__(256) void k_sift_scores(const uint8_t* __restrict__ d1, int n1, const uint8_t* __restrict__ d2,
+                                                     int n2, const int* __restrict__ sum1, const int* __restrict__ sum2,
+                                                     int4* __restrict__ part12, int4* __restrict__ part21, int nbx,
+                                                     int nby) {
+  __shared__ __attribute__((aligned(16))) uint8_t sA[kSiftTile * kSiftPitch];
+  __shared__ __attribute__((aligned(16))) uint8_t sB[kSiftTile * kSiftPitch];
+  __shared__ int sSumA[kSiftTile], sSumB[kSiftTile];
+  __shared__ int4 sMerge[2][2][64];   // [direction][wave half][column in the 64-wide half]... see below
+  const int bx = blockIdx.x, by = blockIdx.y;           // bx: tile of set 2 (columns), by: tile of set 1 (rows)
+  const int row0 = by * kSiftTile, col0 = bx * kSiftTile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // ---- stage both tiles: 1024 16-B chunks each, re-centred to int8 ----
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = tid + it * 256, r = c >> 3, q = c & 7;
+    uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+    if (row0 + r < n1) va = *reinterpret_cast<const uint4*>(d1 + (size_t)(row0 + r) * 128 + q * 16);
+    if (col0 + r < n2) vb = *reinterpret_cast<const uint4*>(d2 + (size_t)(col0 + r) * 128 + q * 16);
+    va.x ^= 0x80808080u; va.y ^= 0x80808080u; va.z ^= 0x80808080u; va.w ^= 0x80808080u;
+    vb.x ^= 0x80808080u; vb.y ^= 0x80808080u; vb.z ^= 0x80808080u; vb.w ^= 0x80808080u;
+    *reinterpret_cast<uint4*>(sA + r * kSiftPitch + q * 16) = va;
+    *reinterpret_cast<uint4*>(sB + r * kSiftPitch + q * 16) = vb;
+  }
+  if (tid < kSiftTile) {
+    sSumA[tid] = row0 + tid < n1 ? sum1[row0 + tid] : 0;
+    sSumB[tid] = col0 + tid < n2 ? sum2[col0 + tid] : 0;
+  }
+  __syncthreads();
+
+  // ---- 64 x 64 per wavefront, both orientations from the same fragments ----
+  v16i acc1[2][2], acc2[2][2];   // acc1[mt][nt]: rows = set-1, cols = set-2;  acc2[nt][mt]: rows = set-2, cols = set-1
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { acc1[a][b][k] = 0; acc2[a][b][k] = 0; }
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    v4i fa[2], fb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      fa[t] = *reinterpret_cast<const v4i*>(sA + (wr * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
+      fb[t] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc1[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mt], fb[nt], acc1[mt][nt], 0, 0, 0);
+        acc2[nt][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[nt], fa[mt], acc2[nt][mt], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+  // Direction 2 -> 1 (for every set-2 descriptor j the best set-1 rows): acc1, lane owns column j.
+  // The column constant 128*sum2[j] - 128^3 does not change the order inside a column, so the scan runs on
+  // acc + 128*sum1[i] with the thresholds shifted by the constant, which is added back at the end.
+#pragma unroll
+  for (int dir = 0; dir < 2; ++dir) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {               // 32-column tile inside the wavefront's 64 columns
+      // dir 0: columns = set 2 (wc, nt = ct), rows = set 1 (wr, mt);  dir 1: columns = set 1 (wr, mt = ct), rows = set 2 (wc, nt)
+      const int ccol = (dir == 0 ? wc : wr) * 64 + ct * 32 + lr;            // column inside the 128 tile
+      const int cconst = 128 * (dir == 0 ? sSumB[ccol] : sSumA[ccol]) - kSiftConst;
+      int best = -cconst, second = -cconst, arg = -1;                        // true values start at 0 (sift.cc:66-68)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const v16i& acc = dir == 0 ? acc1[rt][ct] : acc2[rt][ct];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int rrow = (dir == 0 ? wr : wc) * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+          const int v = acc[reg] + 128 * (dir == 0 ? sSumA[rrow] : sSumB[rrow]);
+          top2_update(v, (dir == 0 ? row0 : col0) + rrow, best, second, arg);
+        }
+      }
+      // the two lane halves hold interleaved rows of the same column
+      {
+        const int b2 = __shfl_xor(best, 32), s2 = __shfl_xor(second, 32), a2 = __shfl_xor(arg, 32);
+        top2_merge(b2, s2, a2, best, second, arg);
+      }
+      // merge the two wavefronts that share these columns (dir 0: wr = 0,1; dir 1: wc = 0,1) through LDS
+      const int other = dir == 0 ? wr : wc;          // which of the two row halves this wavefront holds
+      const int colhalf = dir == 0 ? wc : wr;        // which 64-column half
+      if (other == 1 && lh == 0) sMerge[dir][colhalf][ct * 32 + lr] = make_int4(best, second, arg, 0);
+      __syncthreads();
+      if (other == 0 && lh == 0) {
+        const int4 o = sMerge[dir][colhalf][ct * 32 + lr];
+        top2_merge(o.x, o.y, o.z, best, second, arg);   // rows of `other == 1` are higher: ties keep ours
+        best += cconst;
+        second += cconst;
+        const int gcol = (dir == 0 ? col0 : row0) + ccol;
+        if (dir == 0) { if (gcol < n2) part21[(size_t)gcol * nby + by] = make_int4(best, second, arg, 0); }
+        else { if (gcol < n1) part12[(size_t)gcol * nbx + bx] = make_int4(best, second, arg, 0); }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// sift.cc:72-104: merge the per-tile triples in ascending tile order, then the distance / ratio tests
+__global__ void k_sift_finalize(const int4* __restrict__ part, int n, int nb, float max_ratio, float max_distance,
+                                int* __restrict__ match) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int best = 0, second = 0, arg = -1;
+  for (int b = 0; b < nb; ++b) {
+    const int4 p = part[(size_t)i * nb + b];
+    // ascending order: an equal best from a later tile does not replace the earlier one (strict >)
+    const int nsecond = max(max(second, p.y), min(best, p.x));
+    if (p.x > best) { arg = p.z; best = p.x; }
+    second = nsecond;
+  }
+  int m = -1;
+  if (arg != -1) {
+    const float kDistNorm = 1.0f / (512.0f * 512.0f);
+    const float bn = acosf(fminf(kDistNorm * (float)best, 1.0f));
+    if (!(bn > max_distance)) {
+      const float sn = acosf(fminf(kDistNorm * (float)second, 1.0f));
+      if (!(bn >= max_ratio * sn)) m = arg;
+    }
+  }
+  match[i] = m;
+}
+
+// sift.cc:118-143: keep flags, in set-1 order
+__global__ void k_sift_keep(const int* __restrict__ m12, const int* __restrict__ m21, int n1, int cross_check,
+                            uint32_t* __restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n1) return;
+  const int j = m12[i];
+  bool k = j != -1;
+  if (k && cross_check) k = (m21[j] != -1) && (m21[j] == i);
+  keep[i] = k ? 1u : 0u;
+}
+__global__ void k_sift_compact(const int* __restrict__ m12, const uint32_t* __restrict__ keep,
+                               const uint32_t* __restrict__ pos, int n1, uint32_t* __restrict__ matches,
+                               int* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n1) return;
+  if (keep[i]) { matches[2 * pos[i]] = (uint32_t)i; matches[2 * pos[i] + 1] = (uint32_t)m12[i]; }
+  if (i == n1 - 1) *count = (int)(pos[i] + keep[i]);
+}
+
+struct SiftScratch {
+  DevBuf<uint8_t> d1, d2;
+  DevBuf<int> sum1, sum2, m12, m21, count;
+  DevBuf<int4> part12, part21;
+  DevBuf<uint32_t> keep, pos, matches;
+  DevBuf<char> tmp;
+};
+static SiftScratch* g_sift[64] = {nullptr};
+static std::mutex g_sift_mu;
+
+static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uint8_t* d_d2, int n2, float max_ratio,
+                              float max_distance, int cross_check, int* d_m12, int* d_m21, uint32_t* d_matches,
+                              int* d_count, SiftScratch& sc, hipStream_t s) {
+  const int nby = (n1 + kSiftTile - 1) / kSiftTile, nbx = (n2 + kSiftTile - 1) / kSiftTile;
+  PCD_TRY(sc.sum1.reserve(n1)); PCD_TRY(sc.sum2.reserve(n2));
+  PCD_TRY(sc.part12.reserve((size_t)n1 * nbx)); PCD_TRY(sc.part21.reserve((size_t)n2 * nby));
+  PCD_TRY(sc.keep.reserve(n1)); PCD_TRY(sc.pos.reserve(n1));
+  {
+    ScopedKernelTimer t("sift_rowsum", s);
+    hipLaunchKernelGGL(k_sift_rowsum, dim3(div_up(n1, 256)), dim3(256), 0, s, d_d1, n1, sc.sum1.p);
+    hipLaunchKernelGGL(k_sift_rowsum, dim3(div_up(n2, 256)), dim3(256), 0, s, d_d2, n2, sc.sum2.p);
+  }
+  {
+    ScopedKernelTimer t("sift_scores", s);
+    hipLaunchKernelGGL(k_sift_scores, dim3(nbx, nby), dim3(256), 0, s, d_d1, n1, d_d2, n2, sc.sum1.p, sc.sum2.p,
+                       sc.part12.p, sc.part21.p, nbx, nby);
+  }
+  {
+    ScopedKernelTimer t("sift_finalize", s);
+    hipLaunchKernelGGL(k_sift_finalize, dim3(div_up(n1, 256)), dim3(256), 0, s, sc.part12.p, n1, nbx, max_ratio,
+                       max_distance, d_m12);
+    hipLaunchKernelGGL(k_sift_finalize, dim3(div_up(n2, 256)), dim3(256), 0, s, sc.part21.p, n2, nby, max_ratio,
+                       max_distance, d_m21);
+    hipLaunchKernelGGL(k_sift_keep, dim3(div_up(n1, 256)), dim3(256), 0, s, d_m12, d_m21, n1, cross_check, sc.keep.p);
+    size_t tb = 0;
+    PCD_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, sc.keep.p, sc.pos.p, 0u, (size_t)n1, rocprim::plus<uint32_t>(), s));
+    PCD_TRY(sc.tmp.reserve(tb));
+    PCD_HIP_TRY(rocprim::exclusive_scan(sc.tmp.p, tb, sc.keep.p, sc.pos.p, 0u, (size_t)n1, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(k_sift_compact, dim3(div_up(n1, 256)), dim3(256), 0, s, d_m12, sc.keep.p, sc.pos.p, n1,
+                       d_matches, d_count);
+  }
+  PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
+
+}  // namespace pcd
+
+using namespace pcd;
+
+extern "C" {
+
+pcd_status pcd_sift_match_device(int device, const uint8_t* d_desc1, int n1, const uint8_t* d_desc2, int n2,
+                                 float max_ratio, float max_distance, int cross_check, int32_t* d_m12,
+                                 int32_t* d_m21, uint32_t* d_matches, int32_t* d_num_matches, void* stream) {
+  PCD_REQUIRE(n1 >= 0 && n2 >= 0 && d_num_matches, "sizes / count pointer");
+  PCD_TRY(require_device(device));
+  hipStream_t s = (hipStream_t)stream;
+  if (n1 == 0 || n2 == 0) {   // MatchSiftFeaturesCPU with an empty set: no matches (sift_test.cc:311-318)
+    PCD_HIP_TRY(hipMemsetAsync(d_num_matches, 0, sizeof(int32_t), s));
+    if (n1 && d_m12) PCD_HIP_TRY(hipMemsetAsync(d_m12, 0xFF, sizeof(int32_t) * n1, s));
+    if (n2 && d_m21) PCD_HIP_TRY(hipMemsetAsync(d_m21, 0xFF, sizeof(int32_t) * n2, s));
+    return PCD_OK;
+  }
+  PCD_REQUIRE(d_desc1 && d_desc2 && d_m12 && d_m21 && d_matches, "null pointer");
+  PCD_REQUIRE(device < 64, "device ordinal");
+  std::lock_guard<std::mutex> g(g_sift_mu);
+  if (!g_sift[device]) g_sift[device] = new SiftScratch();
+  return sift_device(device, d_desc1, n1, d_desc2, n2, max_ratio, max_distance, cross_check, d_m12, d_m21, d_matches,
+                     d_num_matches, *g_sift[device], s);
+}
+
+pcd_status pcd_sift_match(int device, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float max_ratio,
+                          float max_distance, int cross_check, uint32_t* matches, int32_t* num_matches) {
+  PCD_REQUIRE(num_matches && n1 >= 0 && n2 >= 0, "sizes / count pointer");
+  *num_matches = 0;
+  if (n1 == 0 || n2 == 0) return PCD_OK;
+  PCD_REQUIRE(desc1 && desc2 && matches, "null pointer");
+  PCD_REQUIRE(device >= 0 && device < 64, "device ordinal");
+  PCD_TRY(require_device(device));
+  SiftScratch* sc;
+  {
+    std::lock_guard<std::mutex> g(g_sift_mu);
+    if (!g_sift[device]) g_sift[device] = new SiftScratch();
+    sc = g_sift[device];
+  }
+  PCD_TRY(sc->d1.reserve((size_t)n1 * 128)); PCD_TRY(sc->d2.reserve((size_t)n2 * 128));
+  PCD_TRY(sc->m12.reserve(n1)); PCD_TRY(sc->m21.reserve(n2)); PCD_TRY(sc->matches.reserve(2 * (size_t)n1));
+  PCD_TRY(sc->count.reserve(1));
+  hipStream_t s = nullptr;
+  PCD_HIP_TRY(hipMemcpyAsync(sc->d1.p, desc1, (size_t)n1 * 128, hipMemcpyHostToDevice, s));
+  PCD_HIP_TRY(hipMemcpyAsync(sc->d2.p, desc2, (size_t)n2 * 128, hipMemcpyHostToDevice, s));
+  PCD_TRY(pcd_sift_match_device(device, sc->d1.p, n1, sc->d2.p, n2, max_ratio, max_distance, cross_check, sc->m12.p,
+                                sc->m21.p, sc->matches.p, sc->count.p, s));
+  int cnt = 0;
+  PCD_HIP_TRY(hipMemcpyAsync(&cnt, sc->count.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  PCD_HIP_TRY(hipStreamSynchronize(s));
+  if (cnt) PCD_HIP_TRY(hipMemcpy(matches, sc->matches.p, 2 * (size_t)cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  *num_matches = cnt;
+  return PCD_OK;
+}
+
+}  // extern "C"

@@ -89,6 +89,7 @@ ABI_SYMBOLS = [
     "pcd_camera_num_params", "pcd_ba_create", "pcd_ba_destroy", "pcd_ba_set_parameters",
     "pcd_ba_evaluate", "pcd_ba_evaluate_device", "pcd_ba_device_parameters",
     "pcd_profile_enable", "pcd_profile_reset", "pcd_profile_get", "pcd_nn_last_stats",
+    "pcd_sift_match", "pcd_sift_match_device",
 ]
 
 _LIB = None
@@ -274,6 +275,30 @@ def associate_from_payload_device(device, d_q, Q, d_max_range, mr_count, gate_mo
                                                   "nn_idx", "nn_sqdist")])
     _check(lib().pcd_associate_from_payload_device(device, _ptr(d_q), Q, _ptr(d_max_range), mr_count, gate_mode,
                                                    _ptr(d_keys), _ptr(d_payload), C.byref(ao), C.c_void_p(stream)))
+
+
+def sift_match(d1, d2, max_ratio=0.8, max_distance=0.7, cross_check=True, device=0):
+    """MatchSiftFeaturesCPUBruteForce semantics on the GPU: returns matches [M][2] uint32"""
+    d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 128)
+    d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 128)
+    n1, n2 = d1.shape[0], d2.shape[0]
+    m = np.zeros((max(n1, 1), 2), np.uint32)
+    cnt = C.c_int32(0)
+    L = lib()
+    L.pcd_sift_match.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int,
+                                 C.c_void_p, C.POINTER(C.c_int32)]
+    _check(L.pcd_sift_match(device, _vp(d1) if n1 else None, n1, _vp(d2) if n2 else None, n2, max_ratio,
+                            max_distance, int(cross_check), _vp(m), C.byref(cnt)))
+    return m[:cnt.value].copy()
+
+
+def sift_match_device(d_d1, n1, d_d2, n2, d_m12, d_m21, d_matches, d_count, max_ratio=0.8, max_distance=0.7,
+                      cross_check=True, device=0, stream=0):
+    L = lib()
+    L.pcd_sift_match_device.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(L.pcd_sift_match_device(device, _ptr(d_d1), n1, _ptr(d_d2), n2, max_ratio, max_distance, int(cross_check),
+                                   _ptr(d_m12), _ptr(d_m21), _ptr(d_matches), _ptr(d_count), C.c_void_p(stream)))
 
 
 def search_range_schedule(opt_num, kd_max=1.5, kd_min=0.2, drop=0.1):

@@ -275,6 +275,24 @@ pcd_status pcd_ba_evaluate_device(pcd_ba* ba, const pcd_ba_out* d_out, void* str
 pcd_status pcd_ba_device_parameters(pcd_ba* ba, double** d_poses, double** d_points);
 
 /* ------------------------------------------------------------------------
+ * Exact SIFT descriptor matching (stretch row a19)
+ *   replaces feature/sift.cc:1041-1054 MatchSiftFeaturesCPUBruteForce =
+ *     feature/sift.cc:171-204 ComputeSiftDistanceMatrix (int32 dot of uint8 x 128) +
+ *     feature/sift.cc:55-144  FindBestMatches[OneWay]BruteForce (ratio / distance tests, cross check)
+ *   -- the exact result the reference's GPU path approximates with lib/SiftGPU SiftMatchGPU::GetSiftMatch
+ *   (lib/SiftGPU/SiftGPU.h:268-352).  Defaults of SiftMatchingOptions (feature/sift.h:121-137):
+ *   max_ratio 0.8, max_distance 0.7, cross_check 1.
+ * desc: [n][128] uint8 row-major.  matches: [min(n1, ...)<= n1][2] = (point2D_idx1, point2D_idx2) in
+ * ascending idx1, exactly the order of the reference's FeatureMatches vector.
+ * --------------------------------------------------------------------- */
+pcd_status pcd_sift_match(int device, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float max_ratio,
+                          float max_distance, int cross_check, uint32_t* matches /*[n1][2]*/, int32_t* num_matches);
+/* device form: m12 [n1] / m21 [n2] receive the one-way results (-1 = none) as well */
+pcd_status pcd_sift_match_device(int device, const uint8_t* d_desc1, int n1, const uint8_t* d_desc2, int n2,
+                                 float max_ratio, float max_distance, int cross_check, int32_t* d_m12,
+                                 int32_t* d_m21, uint32_t* d_matches, int32_t* d_num_matches, void* stream);
+
+/* ------------------------------------------------------------------------
  * Profiling hooks used by bench.py (HIP events on the launch stream)
  * --------------------------------------------------------------------- */
 typedef struct {

@@ -76,8 +76,53 @@ def lib():
     L.oracle_ba_evaluate_raw.argtypes = [C.POINTER(BAProblem)] + [C.c_void_p] * 6
     L.oracle_ba_normal_equations.restype = C.c_double
     L.oracle_ba_normal_equations.argtypes = [C.POINTER(BAProblem)] + [C.c_void_p] * 5
+    L.oracle_sift_match.restype = C.c_int
+    L.oracle_sift_match.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_float, C.c_float, C.c_int, u32p, i32p, i32p]
+    L.oracle_sift_distance_matrix.restype = None
+    L.oracle_sift_distance_matrix.argtypes = [u8p, C.c_int, u8p, C.c_int, i32p]
+    L.oracle_sift_random_descriptors.restype = None
+    L.oracle_sift_random_descriptors.argtypes = [C.c_int, u8p]
+    L.oracle_sift_renormalize_row.restype = None
+    L.oracle_sift_renormalize_row.argtypes = [f32p, u8p]
     _LIB = L
     return L
+
+
+# ---------------------------------------------------------------- SIFT ----
+def sift_match(d1, d2, max_ratio=0.8, max_distance=0.7, cross_check=True):
+    """MatchSiftFeaturesCPUBruteForce: returns (matches [M][2] uint32, m12 [n1] int32, m21 [n2] int32)"""
+    d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 128)
+    d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 128)
+    n1, n2 = d1.shape[0], d2.shape[0]
+    m = np.zeros((max(n1, 1), 2), np.uint32)
+    m12 = np.full(max(n1, 1), -1, np.int32)
+    m21 = np.full(max(n2, 1), -1, np.int32)
+    n = lib().oracle_sift_match(d1.reshape(-1) if n1 else np.zeros(1, np.uint8), n1,
+                                d2.reshape(-1) if n2 else np.zeros(1, np.uint8), n2,
+                                max_ratio, max_distance, int(cross_check), m.reshape(-1), m12, m21)
+    return m[:n].copy(), m12[:n1], m21[:n2]
+
+
+def sift_distance_matrix(d1, d2):
+    d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 128)
+    d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 128)
+    out = np.empty((d1.shape[0], d2.shape[0]), np.int32)
+    lib().oracle_sift_distance_matrix(d1.reshape(-1), d1.shape[0], d2.reshape(-1), d2.shape[0], out.reshape(-1))
+    return out
+
+
+def sift_random_descriptors(n):
+    """CreateRandomFeatureDescriptors of src/feature/sift_test.cc:243-253 (mt19937 seed 0)"""
+    out = np.zeros((max(n, 1), 128), np.uint8)
+    if n:
+        lib().oracle_sift_random_descriptors(n, out.reshape(-1))
+    return out[:n].copy()
+
+
+def sift_renormalize_row(row_u8):
+    out = np.zeros(128, np.uint8)
+    lib().oracle_sift_renormalize_row(np.ascontiguousarray(row_u8, np.float32), out)
+    return out
 
 
 # ------------------------------------------------------------------ NN ----

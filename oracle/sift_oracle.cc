@@ -1,0 +1,126 @@
+// oracle/sift_oracle.cc -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// CPU restatement of colmap's exact (brute-force) SIFT descriptor matching, the specification of the
+// GPU matcher.  Only tests/ and bench tooling may load it.
+//
+// Reference lines followed
+//   src/feature/sift.cc:171-204   ComputeSiftDistanceMatrix: int32 dot product of uint8 x 128 rows
+//   src/feature/sift.cc:55-107    FindBestMatchesOneWayBruteForce: best / second best (strict >, ascending
+//                                 scan, both start at 0, best index -1), acos(min(dot / 512^2, 1)),
+//                                 reject if > max_distance, reject if >= max_ratio * second
+//   src/feature/sift.cc:109-144   FindBestMatchesBruteForce: optional cross check
+//   src/feature/sift.h:121-137    SiftMatchingOptions defaults max_ratio 0.8, max_distance 0.7, cross_check true
+//   src/feature/sift_test.cc:243-253  CreateRandomFeatureDescriptors (mt19937 seed 0, pow(U(0,1),2),
+//                                 L2-normalise, round(512 x) truncated to uint8)  -- restated to regenerate
+//                                 the inputs of the reference's known-answer tests (:296-428)
+// PARITY STATUS: pinned by the reference's own expected match counts 2 / 50 / 50,48,49 / 50,48
+// (tests/test_oracle_cpu.py::test_sift_reference_known_answers).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <random>
+#include <vector>
+
+namespace {
+
+// sift.cc:55-107
+size_t one_way(const std::vector<int>& dists, int rows, int cols, bool transposed, float max_ratio,
+               float max_distance, std::vector<int>* matches, int* best_out, int* second_out) {
+  const float kDistNorm = 1.0f / (512.0f * 512.0f);
+  size_t num_matches = 0;
+  matches->assign(rows, -1);
+  for (int i1 = 0; i1 < rows; ++i1) {
+    int best_i2 = -1;
+    int best_dist = 0;
+    int second_best_dist = 0;
+    for (int i2 = 0; i2 < cols; ++i2) {
+      const int dist = transposed ? dists[(size_t)i2 * rows + i1] : dists[(size_t)i1 * cols + i2];
+      if (dist > best_dist) {
+        best_i2 = i2;
+        second_best_dist = best_dist;
+        best_dist = dist;
+      } else if (dist > second_best_dist) {
+        second_best_dist = dist;
+      }
+    }
+    if (best_out) { best_out[i1] = best_dist; second_out[i1] = second_best_dist; }
+    if (best_i2 == -1) continue;
+    const float best_dist_normed = std::acos(std::min(kDistNorm * best_dist, 1.0f));
+    if (best_dist_normed > max_distance) continue;
+    const float second_best_dist_normed = std::acos(std::min(kDistNorm * second_best_dist, 1.0f));
+    if (best_dist_normed >= max_ratio * second_best_dist_normed) continue;
+    num_matches += 1;
+    (*matches)[i1] = best_i2;
+  }
+  return num_matches;
+}
+
+}  // namespace
+
+extern "C" {
+
+// sift.cc:171-204 without guided filter: dists [n1][n2] row-major
+void oracle_sift_distance_matrix(const uint8_t* d1, int n1, const uint8_t* d2, int n2, int32_t* dists) {
+  for (int i1 = 0; i1 < n1; ++i1)
+    for (int i2 = 0; i2 < n2; ++i2) {
+      int acc = 0;
+      for (int k = 0; k < 128; ++k) acc += (int)d1[(size_t)i1 * 128 + k] * (int)d2[(size_t)i2 * 128 + k];
+      dists[(size_t)i1 * n2 + i2] = acc;
+    }
+}
+
+// MatchSiftFeaturesCPUBruteForce (sift.cc:1041-1054).  matches: [min(n1,n2)... n1][2]; returns the count.
+// m12 / m21 (optional, n1 / n2 ints): the one-way results before the cross check.
+int oracle_sift_match(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float max_ratio, float max_distance,
+                      int cross_check, uint32_t* matches, int32_t* m12_out, int32_t* m21_out) {
+  if (n1 == 0 || n2 == 0) return 0;
+  std::vector<int> dists((size_t)n1 * n2);
+  oracle_sift_distance_matrix(d1, n1, d2, n2, dists.data());
+  std::vector<int> m12, m21;
+  one_way(dists, n1, n2, false, max_ratio, max_distance, &m12, nullptr, nullptr);
+  one_way(dists, n2, n1, true, max_ratio, max_distance, &m21, nullptr, nullptr);
+  if (m12_out) std::copy(m12.begin(), m12.end(), m12_out);
+  if (m21_out) std::copy(m21.begin(), m21.end(), m21_out);
+  int n = 0;
+  for (int i1 = 0; i1 < n1; ++i1) {
+    if (m12[i1] == -1) continue;
+    if (cross_check && !(m21[m12[i1]] != -1 && m21[m12[i1]] == i1)) continue;
+    matches[2 * n] = (uint32_t)i1;
+    matches[2 * n + 1] = (uint32_t)m12[i1];
+    ++n;
+  }
+  return n;
+}
+
+// sift_test.cc:243-253 + feature/utils.cc:47-77.  out: [n][128] uint8
+void oracle_sift_random_descriptors(int n, uint8_t* out) {
+  std::mt19937 prng(0);                                   // SetPRNGSeed(0), util/random.cc:38-48
+  std::vector<float> d((size_t)n * 128);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < 128; ++j) {
+      std::uniform_real_distribution<float> u(0.0f, 1.0f);   // RandomReal<float>, util/random.h
+      d[(size_t)i * 128 + j] = std::pow(u(prng), 2.0f);
+    }
+  for (int i = 0; i < n; ++i) {
+    float sq = 0.f;
+    for (int j = 0; j < 128; ++j) sq += d[(size_t)i * 128 + j] * d[(size_t)i * 128 + j];
+    const float norm = std::sqrt(sq);                      // rowwise().normalized()
+    for (int j = 0; j < 128; ++j) {
+      const float scaled = std::round(512.0f * (d[(size_t)i * 128 + j] / norm));
+      out[(size_t)i * 128 + j] = (uint8_t)std::min(255.0f, std::max(0.0f, scaled));   // TruncateCast
+    }
+  }
+}
+
+// L2-normalise one float row and convert (used by the ratio test case, sift_test.cc:393-399)
+void oracle_sift_renormalize_row(const float* row, uint8_t* out) {
+  float sq = 0.f;
+  for (int j = 0; j < 128; ++j) sq += row[j] * row[j];
+  const float norm = std::sqrt(sq);
+  for (int j = 0; j < 128; ++j) {
+    const float scaled = std::round(512.0f * (row[j] / norm));
+    out[j] = (uint8_t)std::min(255.0f, std::max(0.0f, scaled));
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+"""CPU tests pinning the SIFT-matching oracle with the reference's own known answers
+(src/feature/sift_test.cc:296-428, brute-force matcher)."""
+import numpy as np
+
+
+def sift_reference_cases(po):
+    """Inputs and expected match counts of src/feature/sift_test.cc:296-428 (default SiftMatchingOptions:
+    max_ratio 0.8, max_distance 0.7, cross_check true).  Yields (name, d1, d2, options, expected_count)."""
+    d2f = po.sift_random_descriptors(2)
+    yield "two reversed", d2f, d2f[::-1].copy(), {}, 2                          # :299-309
+    e = np.zeros((0, 128), np.uint8)
+    yield "empty 1", e, d2f, {}, 0                                              # :311-318
+    yield "empty 2", d2f, e, {}, 0
+    yield "empty both", e, e, {}, 0
+    d50 = po.sift_random_descriptors(50)
+    yield "50 reversed", d50, d50[::-1].copy(), {}, 50                          # :371-377
+    yield "50 identical", d50, d50.copy(), {}, 50                               # :380-386
+    mod = d50.copy()                                                            # :387-405 ratio test
+    mod[49] = mod[0]
+    mod[0, 0] = np.uint8((int(mod[0, 0]) + 50) & 255)
+    mod[0] = po.sift_renormalize_row(mod[0])
+    mod[49, 0] = np.uint8((int(mod[49, 0]) + 100) & 255)
+    mod[49] = po.sift_renormalize_row(mod[49])
+    yield "ratio 0.4", d50[:49].copy(), mod, dict(max_ratio=0.4), 48
+    yield "ratio 0.5", d50, mod, dict(max_ratio=0.5), 49
+    a = d50.copy()                                                              # :407-421 cross check
+    a[0] = a[1]
+    yield "no cross check", a, d50.copy(), dict(cross_check=False), 50
+    yield "cross check", a, d50.copy(), dict(cross_check=True), 48
+
+
+def test_sift_reference_known_answers(oracle):
+    for name, d1, d2, opt, expected in sift_reference_cases(oracle):
+        m, m12, m21 = oracle.sift_match(d1, d2, **opt)
+        assert len(m) == expected, (name, len(m), expected)
+        if name == "two reversed":
+            assert m.tolist() == [[0, 1], [1, 0]]
+
+
+def test_sift_distance_matrix_and_one_way_rules(oracle):
+    rng = np.random.default_rng(3)
+    d1 = rng.integers(0, 256, (40, 128), dtype=np.uint8)
+    d2 = rng.integers(0, 256, (70, 128), dtype=np.uint8)
+    S = oracle.sift_distance_matrix(d1, d2)
+    assert np.array_equal(S, d1.astype(np.int64) @ d2.astype(np.int64).T)       # int32 dot, sift.cc:183-199
+    # all-zero descriptors never match (best must be > 0); duplicates fail the ratio test (best == second)
+    z = np.zeros((3, 128), np.uint8)
+    assert len(oracle.sift_match(z, d2)[0]) == 0
+    d = oracle.sift_random_descriptors(10)
+    dd = np.concatenate([d, d[:1]])                                              # d[0] appears twice in set 2
+    m, m12, m21 = oracle.sift_match(d, dd, cross_check=False)
+    assert m12[0] == -1 and (m12[1:] == np.arange(1, 10)).all()

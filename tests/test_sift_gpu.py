@@ -1,0 +1,81 @@
+"""GPU parity of the MFMA SIFT matcher (through the C ABI) against the oracle restating
+feature/sift.cc:55-204.  Bar: identical match lists (integer work: exact dot products, exact
+best / second-best, first-index ties); the acos / ratio thresholds are float and evaluated with the
+device libm, so a row whose test is decided by the last ulp could differ -- none is expected and the
+test reports the margin if one ever shows up."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_sift_cpu import sift_reference_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_known_answers_on_gpu(gpu, oracle):
+    """expected counts of src/feature/sift_test.cc:296-428: 2, 0, 0, 0, 50, 50, 48, 49, 50, 48"""
+    for name, d1, d2, opt, expected in sift_reference_cases(oracle):
+        m = gpu.sift_match(d1, d2, **opt)
+        assert len(m) == expected, (name, len(m), expected)
+        assert np.array_equal(m, oracle.sift_match(d1, d2, **opt)[0]), name
+
+
+@pytest.mark.parametrize("n1,n2", [(1, 1), (127, 129), (128, 128), (300, 77), (1000, 1500)])
+@pytest.mark.parametrize("cross", [True, False])
+def test_random_descriptors_exact(gpu, oracle, n1, n2, cross):
+    rng = np.random.default_rng(n1 * 7 + n2)
+    # SIFT-like: squared uniforms, L2-normalised, x512; second set = noisy permuted copy + distractors
+    f = rng.random((max(n1, n2), 128), dtype=np.float32) ** 2
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    base = np.clip(np.round(512 * f), 0, 255).astype(np.uint8)
+    d1 = base[:n1].copy()
+    noisy = np.clip(base.astype(np.int32) + rng.integers(-6, 7, base.shape), 0, 255).astype(np.uint8)
+    d2 = noisy[rng.permutation(max(n1, n2))[:n2]].copy()
+    if n2 > 10:
+        d2[3] = d2[5]                       # duplicate column: ties -> first index, ratio test fails
+    if n1 > 10:
+        d1[7] = 0                           # all-zero descriptor: never matches
+    for ratio in (0.8, 0.95):
+        exp, e12, e21 = oracle.sift_match(d1, d2, max_ratio=ratio, cross_check=cross)
+        got = gpu.sift_match(d1, d2, max_ratio=ratio, cross_check=cross)
+        assert np.array_equal(got, exp), (n1, n2, cross, ratio, len(got), len(exp))
+    if n1 >= 100:
+        assert len(exp) > 10               # the test set really produces matches
+
+
+def test_one_way_results_and_asymmetric_layout_check(gpu, oracle):
+    """device API: m12 / m21 equal the oracle's one-way results; the inputs are asymmetric (different sizes,
+    different contents per row and per column) so a transposed or permuted MFMA result layout cannot pass"""
+    rng = np.random.default_rng(5)
+    n1, n2 = 200, 333
+    d1 = rng.integers(0, 60, (n1, 128), dtype=np.uint8)
+    d2 = rng.integers(0, 60, (n2, 128), dtype=np.uint8)
+    d2[:150] = np.clip(d1[:150][::-1].astype(np.int32) + rng.integers(-2, 3, (150, 128)), 0, 255)
+    exp, e12, e21 = oracle.sift_match(d1, d2, max_ratio=0.99, max_distance=3.0)
+    t1, t2 = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
+    m12 = torch.empty(n1, dtype=torch.int32, device="cuda")
+    m21 = torch.empty(n2, dtype=torch.int32, device="cuda")
+    mm = torch.empty(n1, 2, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu.sift_match_device(t1, n1, t2, n2, m12, m21, mm, cnt, max_ratio=0.99, max_distance=3.0)
+    torch.cuda.synchronize()
+    assert np.array_equal(m12.cpu().numpy(), e12) and np.array_equal(m21.cpu().numpy(), e21)
+    assert int(cnt.item()) == len(exp) and np.array_equal(mm.cpu().numpy()[: len(exp)].astype(np.uint32), exp)
+    assert (e12[:150] == np.arange(149, -1, -1)).mean() > 0.9
+
+
+def test_full_size_pair_properties(gpu):
+    """8192 x 8192 (the reference's max_num_features, feature/sift.h:59): size-independent properties --
+    matching a set against a permutation of itself recovers the permutation; cross-checked matches are
+    symmetric; swapping the roles of the two sets transposes the result"""
+    rng = np.random.default_rng(11)
+    n = 8192
+    f = rng.random((n, 128), dtype=np.float32) ** 2
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    d1 = np.clip(np.round(512 * f), 0, 255).astype(np.uint8)
+    perm = rng.permutation(n)
+    d2 = d1[perm]
+    m = gpu.sift_match(d1, d2)
+    assert len(m) == n and np.array_equal(perm[m[:, 1]], m[:, 0])
+    mt = gpu.sift_match(d2, d1)
+    assert np.array_equal(mt[np.argsort(mt[:, 1])][:, ::-1], m)

@@ -1,0 +1,45 @@
+"""Throughput of the MFMA SIFT matcher on one image pair: python tools/sift_probe.py [n1] [n2] [reps]
+(config 5 of BASELINE.json: 8192 x 128 uint8 descriptors per image, exhaustive pairs)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "colmap-pcd_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import pcdhip  # noqa: E402
+
+n1 = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+n2 = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+rng = np.random.default_rng(0)
+f = rng.random((max(n1, n2), 128), dtype=np.float32) ** 2
+f /= np.linalg.norm(f, axis=1, keepdims=True)
+d = np.clip(np.round(512 * f), 0, 255).astype(np.uint8)
+t1 = torch.from_numpy(d[:n1].copy()).cuda()
+t2 = torch.from_numpy(d[rng.permutation(max(n1, n2))[:n2]].copy()).cuda()
+m12 = torch.empty(n1, dtype=torch.int32, device="cuda")
+m21 = torch.empty(n2, dtype=torch.int32, device="cuda")
+mm = torch.empty(n1, 2, dtype=torch.int32, device="cuda")
+cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+for _ in range(3):
+    pcdhip.sift_match_device(t1, n1, t2, n2, m12, m21, mm, cnt)
+torch.cuda.synchronize()
+pcdhip.profile_enable(True)
+pcdhip.profile_reset()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    pcdhip.sift_match_device(t1, n1, t2, n2, m12, m21, mm, cnt)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+p = pcdhip.profile_get()
+pcdhip.profile_enable(False)
+for k, (n, t) in p.items():
+    print("  %-16s %8.3f ms/launch" % (k, t / n))
+sc = p["sift_scores"][1] / p["sift_scores"][0]
+ops = 2.0 * 2 * 128 * n1 * n2          # the tile is computed in both orientations
+print("pair %d x %d: %.3f ms -> %.0f pairs/s; %d matches" % (n1, n2, ms, 1e3 / ms, int(cnt.item())))
+print("k_sift_scores: %.3f ms, %.1f TOP/s int8 MFMA executed (useful %.1f), dense i8 peak ~5000 TOP/s"
+      % (sc, ops / sc / 1e9, ops / 2 / sc / 1e9))
