@@ -19,11 +19,11 @@
 //                    the group is compared with every staged point.  A query
 //                    is final when its best distance is provably smaller than
 //                    its distance to the boundary of the staged region.
-//   k_nn_fallback    one wavefront per remaining query: rings of 4x4x4-cell
-//                    blocks around the query, pruned with the blocks' tight
-//                    AABBs (nearest block first), until the ring boundary is
-//                    provably farther than the best distance.  Exact for any
-//                    query position, also outside the grid.
+//   k_nn_fallback    one wavefront per remaining query: depth-first, nearest-first
+//                    descent of the 64-ary pyramid of tight AABBs over the grid
+//                    (level 0 = 4x4x4-cell blocks), the 64 children of a node one
+//                    per lane, pruned with the exact float lower bound.  Exact for
+//                    any query position, also outside the grid.
 //
 // Exactness of the pruning (float distances, not real ones):
 //   * AABB bound: lb = l2_simple3(q, clamp(q, lo, hi)) with lo/hi the actual
@@ -31,7 +31,7 @@
 //     point p of the block fl_dist(q,p) >= lb; a block is skipped only if
 //     lb > best (strictly: an equal-distance point with a lower index may hide
 //     in it).
-//   * region / ring bound: margin = min distance from q to the faces of the
+//   * region bound: margin = min distance from q to the faces of the
 //     staged cell range (double).  A point binned outside the range can lie at
 //     most `slack` inside it because of float rounding in the binning
 //     (grid.slack = 9.6e-7 * max(extent, |coord|) >= 4 roundings of 2^-24),
@@ -52,7 +52,6 @@ namespace pcd {
 void free_query_scratch(QueryScratch* s) { delete s; }
 
 constexpr uint64_t kKeyInit = (uint64_t)0x7F7FFFFFu << 32;  // (FLT_MAX, idx 0): nothing with d >= FLT_MAX beats it
-constexpr int kTilePts = 512;                               // LDS tile per wavefront: 512 x 16 B = 8 KiB
 constexpr int kMaxRows = 64;                                // rows of a brick region (one per lane)
 
 // ------------------------------------------------------------ brick math ---
@@ -230,123 +229,6 @@ __device__ __forceinline__ double proven_bound(const GridParams& g, float qx, fl
 #include "brick_kernel.h"
 namespace pcd {
 
-#if 0  // first version of the brick kernel (register staging, one reduction per query); kept for reference only
-template <int G>
-__global__ __launch_bounds__(256) void k_nn_brick_v1(GridParams g, BrickParams b, const float4* __restrict__ sorted,
-                                                  const uint32_t* __restrict__ cell_start,
-                                                  const float4* __restrict__ qf4, const uint32_t* __restrict__ q_order,
-                                                  const uint4* __restrict__ items, NnCounters* __restrict__ ctr,
-                                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ fb_list,
-                                                  int collect_stats) {
-  __shared__ float4 s_tile[4][kTilePts];
-  __shared__ uint32_t s_rowoff[4][kMaxRows];
-  __shared__ uint32_t s_rowsrc[4][kMaxRows];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float4* tile = s_tile[wave];
-  uint32_t* rowoff = s_rowoff[wave];
-  uint32_t* rowsrc = s_rowsrc[wave];
-  const uint32_t nitems = ctr->nitems;
-  const uint32_t nwaves = gridDim.x * 4;
-  unsigned long long st_staged = 0, st_pairs = 0, st_groups = 0;
-
-  for (uint32_t item = blockIdx.x * 4 + wave; item < nitems; item += nwaves) {
-    const uint4 it = items[item];
-    const uint32_t first = it.x, brick = it.y, cnt = it.z;
-    // --- queries of the group (wave-uniform copies) ---
-    uint32_t my_qi = 0;
-    float4 my_q = make_float4(0, 0, 0, 0);
-    if (lane < (int)cnt) {
-      my_qi = q_order[first + lane];
-      my_q = qf4[my_qi];
-    }
-    float qx[G], qy[G], qz[G];
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-      // queries beyond cnt repeat query 0: their results are never written
-      const int src = k < (int)cnt ? k : 0;
-      qx[k] = readlane_f(my_q.x, src);
-      qy[k] = readlane_f(my_q.y, src);
-      qz[k] = readlane_f(my_q.z, src);
-    }
-    // --- staged region: brick grown by R cells, clipped to the grid ---
-    const int bx = (int)(brick % b.nb[0]), by = (int)((brick / b.nb[0]) % b.nb[1]),
-              bz = (int)(brick / ((uint32_t)b.nb[0] * b.nb[1]));
-    int c0[3] = {max(bx * b.B - b.R, 0), max(by * b.B - b.R, 0), max(bz * b.B - b.R, 0)};
-    int c1[3] = {min(bx * b.B + b.B + b.R, g.dims[0]), min(by * b.B + b.B + b.R, g.dims[1]),
-                 min(bz * b.B + b.B + b.R, g.dims[2])};
-    const int ny = c1[1] - c0[1], nrows = ny * (c1[2] - c0[2]);
-    uint32_t s = 0, len = 0;
-    if (lane < nrows) {
-      const int cy = c0[1] + lane % ny, cz = c0[2] + lane / ny;
-      const uint64_t rowbase = ((uint64_t)cz * g.dims[1] + cy) * g.dims[0];
-      s = cell_start[rowbase + c0[0]];
-      len = cell_start[rowbase + c1[0]] - s;
-    }
-    uint32_t T;
-    const uint32_t off = wave_excl_scan_u32(len, T);
-    rowoff[lane] = off;
-    rowsrc[lane] = s;
-
-    uint64_t best[G];
-#pragma unroll
-    for (int k = 0; k < G; ++k) best[k] = kKeyInit;
-
-    for (uint32_t tb = 0; tb < T; tb += kTilePts) {
-      const int tn = (int)min((uint32_t)kTilePts, T - tb);
-      __builtin_amdgcn_wave_barrier();
-      // stage: flat copy of the concatenated row ranges (row of element j by binary search)
-      for (int j = lane; j < tn; j += 64) {
-        const uint32_t gi = tb + j;
-        int r = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1)
-          if (rowoff[r + step] <= gi) r += step;   // largest r with rowoff[r] <= gi (empty rows share offsets)
-        tile[j] = sorted[rowsrc[r] + (gi - rowoff[r])];
-      }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      // compare: lanes = staged points, queries wave-uniform
-      for (int j = lane; j < tn; j += 64) {
-        const float4 p = tile[j];
-        const uint32_t pi = __float_as_uint(p.w);
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-          const float d = l2_simple3(qx[k], qy[k], qz[k], p.x, p.y, p.z);
-          const uint64_t key = make_key(d, pi);
-          best[k] = key < best[k] ? key : best[k];
-        }
-      }
-    }
-    // --- per-wavefront min reductions, one per query ---
-    uint64_t mine = kKeyInit;
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-      const uint64_t r = wave_min_u64(best[k]);
-      if (lane == k) mine = r;
-    }
-    bool unproven = false;
-    if (lane < (int)cnt) {
-      const double bound = proven_bound(g, my_q.x, my_q.y, my_q.z, c0, c1);
-      const double bd = (double)__uint_as_float((uint32_t)(mine >> 32));
-      unproven = !(bd < bound);
-      keys[my_qi] = mine;  // final, or the starting bound of the fallback
-    }
-    const unsigned long long um = __ballot(unproven);
-    if (um) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&ctr->fb_count, (uint32_t)__popcll(um));
-      base = __shfl(base, 0);
-      if (unproven) fb_list[base + __popcll(um & ((1ull << lane) - 1))] = my_qi;
-    }
-    if (collect_stats) { st_staged += T; st_pairs += (unsigned long long)T * cnt; st_groups += 1; }
-  }
-  if (collect_stats && lane == 0) {
-    atomicAdd(&ctr->staged_points, st_staged);
-    atomicAdd(&ctr->pair_evals, st_pairs);
-    atomicAdd(&ctr->brick_groups, st_groups);
-  }
-}
-#endif
 
 // --------------------------------------------------------- exact fallback ---
 // scan the point range [s,e): lanes stride over it
