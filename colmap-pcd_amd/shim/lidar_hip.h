@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/pcdhip.h"
+#include "ply_reader.h"
 
 namespace colmap_hip {
 
@@ -56,6 +57,14 @@ class PointCloudProcess {
   ~PointCloudProcess() { pcd_cloud_destroy(cloud_); }
   PointCloudProcess(const PointCloudProcess&) = delete;
   PointCloudProcess& operator=(const PointCloudProcess&) = delete;
+
+  // lidar/ply.cc:9-31: load the PLY at path_, transform, index.  Returns false when the file cannot be
+  // read (the reference prints and returns false; callers only print, sfm/incremental_mapper.cc:201-205).
+  bool Initialize() {
+    std::vector<float> xyz, nrm;
+    if (!ReadPlyXYZNormal(path_, &xyz, &nrm)) return false;
+    return InitializeFromRawCloud(xyz.data(), nrm.data(), xyz.size() / 3);
+  }
 
   // lidar/ply.cc:9-31 after pcl::io::loadPLYFile: rows as stored in the PLY (LiDAR frame, lidarpt::Point
   // AoS 32 B or two arrays).  Applies the axis swap + NaN filter of ply.cc:33-57 and builds the index.

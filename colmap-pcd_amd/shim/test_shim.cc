@@ -156,6 +156,54 @@ static void TestLidarBlocks() {   // optim/bundle_adjustment.cc:993-1040 weights
   CHECK_EQ(ba3.obs_image_.size(), 10u);
 }
 
+// PLY ingest (lidar/ply.cc:14 pcl::io::loadPLYFile contract): ascii and binary, extra properties, nx/ny/nz
+static std::string WritePly(bool binary, bool short_names, const std::vector<float>& xyz, const std::vector<float>& nrm) {
+  const std::string path = std::string("/tmp/pcdhip_test_") + (binary ? "bin" : "ascii") + (short_names ? "_nx" : "") + ".ply";
+  FILE* f = std::fopen(path.c_str(), "wb");
+  const size_t n = xyz.size() / 3;
+  std::fprintf(f, "ply\nformat %s 1.0\ncomment test\nelement vertex %zu\n", binary ? "binary_little_endian" : "ascii", n);
+  std::fprintf(f, "property float x\nproperty float y\nproperty float z\nproperty uchar intensity\n");
+  if (short_names) std::fprintf(f, "property double nx\nproperty double ny\nproperty double nz\n");
+  else std::fprintf(f, "property float normal_x\nproperty float normal_y\nproperty float normal_z\n");
+  std::fprintf(f, "element face 0\nproperty list uchar int vertex_indices\nend_header\n");
+  for (size_t i = 0; i < n; ++i) {
+    const unsigned char inten = (unsigned char)(i & 255);
+    if (binary) {
+      std::fwrite(&xyz[3 * i], 4, 3, f);
+      std::fwrite(&inten, 1, 1, f);
+      if (short_names) { double d[3] = {nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]}; std::fwrite(d, 8, 3, f); }
+      else std::fwrite(&nrm[3 * i], 4, 3, f);
+    } else {
+      std::fprintf(f, "%.9g %.9g %.9g %d %.9g %.9g %.9g\n", xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], (int)inten,
+                   nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+    }
+  }
+  std::fclose(f);
+  return path;
+}
+
+static void TestPlyReader() {
+  std::vector<float> xyz, nrm;
+  std::mt19937 rng(3);
+  std::uniform_real_distribution<float> u(-50.f, 50.f);
+  for (int i = 0; i < 1000; ++i) for (int k = 0; k < 3; ++k) { xyz.push_back(u(rng)); nrm.push_back(u(rng) / 50.f); }
+  xyz[3 * 17 + 1] = NAN;   // NaN rows survive the reader; the axis swap / filter drops them later
+  for (int variant = 0; variant < 4; ++variant) {
+    const std::string p = WritePly(variant & 1, variant & 2, xyz, nrm);
+    std::vector<float> x2, n2;
+    CHECK(ReadPlyXYZNormal(p, &x2, &n2));
+    CHECK_EQ(x2.size(), xyz.size());
+    bool same = x2.size() == xyz.size();
+    for (size_t i = 0; same && i < xyz.size(); ++i) {
+      same = (std::isnan(xyz[i]) ? std::isnan(x2[i]) : x2[i] == xyz[i]) && n2[i] == nrm[i];
+    }
+    CHECK(same);
+    std::remove(p.c_str());
+  }
+  std::vector<float> a, b;
+  CHECK(!ReadPlyXYZNormal("/tmp/pcdhip_does_not_exist.ply", &a, &b));   // load failure -> false (ply.cc:14-17)
+}
+
 static int TestGpu() {
   if (pcd_device_count() < 1) { std::printf("FAIL: --gpu given but no gfx950 device\n"); return 1; }
   // cloud: plane y = 1 (visual frame) on a 5 cm lattice with normal (0,1,0), given in the raw LiDAR frame
@@ -169,6 +217,19 @@ static int TestGpu() {
   lidar::PointCloudProcess pcp;
   CHECK(pcp.InitializeFromRawCloud(xyz.data(), nrm.data(), xyz.size() / 3));
   CHECK_EQ(pcp.size(), 40000u);
+  {  // the same cloud through PointCloudProcess(path).Initialize() (lidar/ply.cc:9-31) from a binary PLY
+    const std::string ply = WritePly(true, false, xyz, nrm);
+    lidar::PointCloudProcess from_file(ply);
+    CHECK(from_file.Initialize());
+    CHECK_EQ(from_file.size(), 40000u);
+    std::array<double, 3> qq = {2.51, 1.3, 4.02};
+    std::array<double, 6> la{}, lb{};
+    CHECK(pcp.SearchNearestNeiborByKdtree(qq, la) && from_file.SearchNearestNeiborByKdtree(qq, lb));
+    CHECK(la == lb);
+    std::remove(ply.c_str());
+    lidar::PointCloudProcess missing("/tmp/pcdhip_no_such_map.ply");
+    CHECK(!missing.Initialize());
+  }
   std::array<double, 3> q = {2.51, 1.3, 4.02};
   std::array<double, 6> l6{};
   CHECK(pcp.SearchNearestNeiborByKdtree(q, l6));
@@ -218,6 +279,7 @@ int main(int argc, char** argv) {
   TestPartiallyContainedTracks();
   TestForceToOptimizePoint();
   TestLidarBlocks();
+  TestPlyReader();
   if (argc > 1 && std::strcmp(argv[1], "--gpu") == 0) g_fail += TestGpu();
   std::printf(g_fail ? "%d FAILED\n" : "ALL OK\n", g_fail);
   return g_fail ? 1 : 0;
