@@ -130,6 +130,23 @@ __global__ void k_associate_payload(const double* __restrict__ q, uint64_t Q, co
   assoc_core(X, p, nv, found, mr, mode, i, o);
 }
 
+// base/reconstruction.cc:771-805 FilterLidarOutlier: erase the association when the point-to-point distance
+// between the (re-optimised) 3D point and its LiDAR point exceeds the bound of its type
+__global__ void k_filter_lidar_outlier(const double* __restrict__ X, const double* __restrict__ lxyz,
+                                       const uint8_t* __restrict__ type, uint64_t n, double max_proj,
+                                       double max_icp, uint8_t* __restrict__ erase) {
+  const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t e = 0;
+  const uint8_t t = type[i];
+  if (t != PCD_LIDAR_NONE) {
+    const double vx = lxyz[3 * i] - X[3 * i], vy = lxyz[3 * i + 1] - X[3 * i + 1], vz = lxyz[3 * i + 2] - X[3 * i + 2];
+    const double dist = sqrt(vx * vx + vy * vy + vz * vz);
+    e = dist > (t == PCD_LIDAR_PROJ ? max_proj : max_icp) ? 1 : 0;
+  }
+  erase[i] = e;
+}
+
 pcd_status nn_query_device_internal(pcd_cloud* c, const double* d_q, uint64_t Q, int algo, uint64_t* d_keys,
                                     hipStream_t s);
 
@@ -199,6 +216,20 @@ pcd_status pcd_associate_from_payload_device(int device, const double* d_q_xyz, 
   hipLaunchKernelGGL(k_associate_payload, dim3(div_up(Q, 256)), dim3(256), 0, s, d_q_xyz, Q, d_keys, d_payload,
                      gate_mode == PCD_GATE_CONTROLLER ? nullptr : d_max_range, max_range_count, gate_mode,
                      to_dev(d_out));
+  PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
+
+pcd_status pcd_filter_lidar_outlier_device(int device, const double* d_points_xyz, const double* d_lidar_xyz,
+                                           const uint8_t* d_type, uint64_t n, double max_proj_dist_error,
+                                           double max_icp_dist_error, uint8_t* d_erase, void* stream) {
+  PCD_REQUIRE(n == 0 || (d_points_xyz && d_lidar_xyz && d_type && d_erase), "null pointer");
+  if (n == 0) return PCD_OK;
+  PCD_TRY(require_device(device));
+  hipStream_t s = (hipStream_t)stream;
+  ScopedKernelTimer t("filter_lidar_outlier", s);
+  hipLaunchKernelGGL(k_filter_lidar_outlier, dim3(div_up(n, 256)), dim3(256), 0, s, d_points_xyz, d_lidar_xyz, d_type,
+                     n, max_proj_dist_error, max_icp_dist_error, d_erase);
   PCD_HIP_TRY(hipGetLastError());
   return PCD_OK;
 }

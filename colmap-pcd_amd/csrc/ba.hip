@@ -258,6 +258,37 @@ __global__ __launch_bounds__(256) void k_ba_raw(BaDev d, double* __restrict__ re
   }
 }
 
+// Inputs of the post-BA filters, per observation:
+//   sq_err = CalculateSquaredReprojectionError (base/projection.cc:104-117; quaternion normalised first as
+//            base/pose.cc QuaternionRotatePoint does; DBL_MAX when the point is not in front of the camera)
+//   depth  = P.z (FilterObservationsWithNegativeDepth, base/reconstruction.cc:837-855, tests it against eps)
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_ba_obs_errors(BaDev d, double* __restrict__ sq_err, double* __restrict__ depth) {
+  const uint64_t o = blockIdx.x * (uint64_t)256 + threadIdx.x;
+  if (o >= d.O) return;
+  const int im = d.obs_image[o], pt = d.obs_point[o];
+  const double* pose = d.poses + 7 * (size_t)im;
+  double q[4] = {pose[0], pose[1], pose[2], pose[3]};
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n == 0.0) { q[0] = 1.0; q[1] = q[2] = q[3] = 0.0; }
+  else { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
+  const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
+  const double cx = q[2] * X[2] - q[3] * X[1], cy = q[3] * X[0] - q[1] * X[2], cz = q[1] * X[1] - q[2] * X[0];
+  const double ux = 2.0 * cx, uy = 2.0 * cy, uz = 2.0 * cz;
+  const double Px = X[0] + q[0] * ux + (q[2] * uz - q[3] * uy) + pose[4];
+  const double Py = X[1] + q[0] * uy + (q[3] * ux - q[1] * uz) + pose[5];
+  const double Pz = X[2] + q[0] * uz + (q[1] * uy - q[2] * ux) + pose[6];
+  if (depth) depth[o] = Pz;
+  if (!sq_err) return;
+  if (Pz < 2.220446049250313e-16) { sq_err[o] = 1.7976931348623157e308; return; }
+  const int cm = d.image_cam[im];
+  const int model = MODEL >= 0 ? MODEL : d.cam_model[cm];
+  D2 x, y;
+  world_to_image_d2(model, d.cam_params + d.cam_off[cm], Px / Pz, Py / Pz, x, y);
+  const double dx = x.a - d.obs_xy[2 * o], dy = y.a - d.obs_xy[2 * o + 1];
+  sq_err[o] = dx * dx + dy * dy;
+}
+
 __global__ __launch_bounds__(256) void k_ba_lidar_raw(BaDev d, double* __restrict__ residuals, double* __restrict__ JL) {
   const uint64_t l = blockIdx.x * (uint64_t)256 + threadIdx.x;
   if (l >= d.L) return;
@@ -506,6 +537,32 @@ pcd_status pcd_ba_evaluate_device(pcd_ba* b, const pcd_ba_out* o, void* stream) 
     hipLaunchKernelGGL(k_ba_lidar_raw, dim3(div_up(b->L, 256)), dim3(256), 0, s, d, o->residuals, o->jac_lidar);
   }
   PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
+
+pcd_status pcd_ba_observation_errors_device(pcd_ba* b, double* d_sq_err, double* d_depth, void* stream) {
+  PCD_REQUIRE(b, "null handle");
+  if (!b->O || (!d_sq_err && !d_depth)) return PCD_OK;
+  PCD_HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  const BaDev d = b->dev();
+  const int model = b->uniform_model;
+  ScopedKernelTimer t("ba_obs_errors", s);
+  PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_obs_errors<M>), dim3(div_up(b->O, 256)), dim3(256), 0, s, d, d_sq_err,
+                                            d_depth));
+  PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
+
+pcd_status pcd_ba_observation_errors(pcd_ba* b, double* sq_err, double* depth) {
+  PCD_REQUIRE(b, "null handle");
+  if (!b->O) return PCD_OK;
+  PCD_HIP_TRY(hipSetDevice(b->device));
+  PCD_TRY(b->o_jq.reserve(b->O));
+  PCD_TRY(b->o_jt.reserve(b->O));
+  PCD_TRY(pcd_ba_observation_errors_device(b, sq_err ? b->o_jq.p : nullptr, depth ? b->o_jt.p : nullptr, nullptr));
+  if (sq_err) PCD_HIP_TRY(hipMemcpy(sq_err, b->o_jq.p, b->O * sizeof(double), hipMemcpyDeviceToHost));
+  if (depth) PCD_HIP_TRY(hipMemcpy(depth, b->o_jt.p, b->O * sizeof(double), hipMemcpyDeviceToHost));
   return PCD_OK;
 }
 

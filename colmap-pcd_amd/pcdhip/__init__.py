@@ -90,6 +90,7 @@ ABI_SYMBOLS = [
     "pcd_ba_evaluate", "pcd_ba_evaluate_device", "pcd_ba_device_parameters",
     "pcd_profile_enable", "pcd_profile_reset", "pcd_profile_get", "pcd_nn_last_stats",
     "pcd_sift_match", "pcd_sift_match_device",
+    "pcd_filter_lidar_outlier_device", "pcd_ba_observation_errors", "pcd_ba_observation_errors_device",
 ]
 
 _LIB = None
@@ -301,6 +302,14 @@ def sift_match_device(d_d1, n1, d_d2, n2, d_m12, d_m21, d_matches, d_count, max_
                                    _ptr(d_m12), _ptr(d_m21), _ptr(d_matches), _ptr(d_count), C.c_void_p(stream)))
 
 
+def filter_lidar_outlier_device(d_points, d_lidar_xyz, d_type, n, max_proj, max_icp, d_erase, device=0, stream=0):
+    L = lib()
+    L.pcd_filter_lidar_outlier_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                                  C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    _check(L.pcd_filter_lidar_outlier_device(device, _ptr(d_points), _ptr(d_lidar_xyz), _ptr(d_type), n, max_proj,
+                                             max_icp, _ptr(d_erase), C.c_void_p(stream)))
+
+
 def search_range_schedule(opt_num, kd_max=1.5, kd_min=0.2, drop=0.1):
     opt_num = np.ascontiguousarray(opt_num, np.int32)
     out = np.empty(opt_num.shape[0], np.float64)
@@ -401,6 +410,15 @@ class BA:
     def evaluate_device(self, d_out, stream=0):
         bo = BAOut(*[_ptr(d_out.get(n)) for n, _ in BAOut._fields_])
         _check(lib().pcd_ba_evaluate_device(self._h, C.byref(bo), C.c_void_p(stream)))
+
+    def observation_errors(self):
+        """(squared reprojection error, camera-frame depth) per observation: inputs of the post-BA filters"""
+        sq = np.empty(self.O)
+        depth = np.empty(self.O)
+        L = lib()
+        L.pcd_ba_observation_errors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.pcd_ba_observation_errors(self._h, _vp(sq), _vp(depth)))
+        return sq, depth
 
     def device_parameters(self):
         a, b = C.c_void_p(), C.c_void_p()

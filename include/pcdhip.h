@@ -168,6 +168,15 @@ pcd_status pcd_associate_from_payload_device(int device, const double* d_q_xyz, 
                                              int gate_mode, const uint64_t* d_keys, const int32_t* d_payload,
                                              const pcd_assoc_out* d_out, void* stream);
 
+/* Post-BA outlier filter of the associations       replaces base/reconstruction.cc:771-805
+ *   Reconstruction::FilterLidarOutlier: erase[i] = 1 when ||lidar_xyz[i] - points_xyz[i]|| exceeds
+ *   max_proj_dist_error (type PCD_LIDAR_PROJ) or max_icp_dist_error (Icp / IcpGround); type 0 rows are
+ *   left alone.  Device pointers (the arrays normally still live in HBM after BA). */
+#define PCD_LIDAR_PROJ 3   /* LidarPointType::Proj: depth-projection associations (not produced here yet) */
+pcd_status pcd_filter_lidar_outlier_device(int device, const double* d_points_xyz, const double* d_lidar_xyz,
+                                           const uint8_t* d_type, uint64_t n, double max_proj_dist_error,
+                                           double max_icp_dist_error, uint8_t* d_erase, void* stream);
+
 /* search-radius schedule, sfm/incremental_mapper.cc:1159-1163, 1423-1427 */
 pcd_status pcd_search_range_schedule(const int32_t* global_opt_num, uint64_t n, double kd_max,
                                      double kd_min, double drop_speed, double* out);
@@ -271,6 +280,14 @@ typedef struct {
 
 pcd_status pcd_ba_evaluate(pcd_ba* ba, const pcd_ba_out* out);                 /* host outputs   */
 pcd_status pcd_ba_evaluate_device(pcd_ba* ba, const pcd_ba_out* d_out, void* stream);  /* device outputs */
+/* Inputs of the post-BA filters, per observation (either pointer may be NULL):
+ *   sq_err[o] = CalculateSquaredReprojectionError (base/projection.cc:104-117), DBL_MAX when the point is not
+ *               in front of the camera -- what FilterPoints3DWithLargeReprojectionError
+ *               (base/reconstruction.cc:1662-1700) and ComputeMeanReprojectionError (:906) consume;
+ *   depth[o]  = z of the point in the camera frame -- FilterObservationsWithNegativeDepth (:837-855) deletes
+ *               observations with depth < DBL_EPSILON. */
+pcd_status pcd_ba_observation_errors(pcd_ba* ba, double* sq_err /*[O]*/, double* depth /*[O]*/);
+pcd_status pcd_ba_observation_errors_device(pcd_ba* ba, double* d_sq_err, double* d_depth, void* stream);
 /* device-side parameter pointers for zero-copy updates: [I][7] and [P][3] doubles */
 pcd_status pcd_ba_device_parameters(pcd_ba* ba, double** d_poses, double** d_points);
 

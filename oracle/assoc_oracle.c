@@ -92,3 +92,20 @@ void oracle_search_range_schedule(const int32_t* opt_num, uint64_t n, double kd_
     out[i] = r;
   }
 }
+
+/* base/reconstruction.cc:771-805 FilterLidarOutlier: an association is dropped when the point-to-point
+ * distance between the (possibly re-optimised) 3D point and its LiDAR point exceeds the bound of its
+ * type (Proj: max_proj_dist_error, Icp / IcpGround: max_icp_dist_error).  type: 0 none (kept untouched),
+ * 1 Icp, 2 IcpGround, 3 Proj.  out[i] = 1 when the association is erased. */
+void oracle_filter_lidar_outlier(const double* X, const double* lidar_xyz, const uint8_t* type, uint64_t n,
+                                 double max_proj_dist_error, double max_icp_dist_error, uint8_t* out) {
+  for (uint64_t i = 0; i < n; ++i) {
+    out[i] = 0;
+    if (type[i] == 0) continue;
+    const double vx = lidar_xyz[3 * i] - X[3 * i], vy = lidar_xyz[3 * i + 1] - X[3 * i + 1],
+                 vz = lidar_xyz[3 * i + 2] - X[3 * i + 2];
+    const double dist = sqrt(vx * vx + vy * vy + vz * vz);
+    const double bound = type[i] == 3 ? max_proj_dist_error : max_icp_dist_error;
+    if (dist > bound) out[i] = 1;
+  }
+}

@@ -353,6 +353,34 @@ void oracle_ba_evaluate_raw(const oracle_ba_problem* p, double* residuals, doubl
   }
 }
 
+// Post-BA filters' inputs.  Per observation:
+//   sq_err = CalculateSquaredReprojectionError (base/projection.cc:104-117): P = R(q/|q|) X + t
+//            (base/pose.cc QuaternionRotatePoint normalises first; |q| == 0 -> identity),
+//            DBL_MAX if P.z < eps, else ||WorldToImage(P.xy / P.z) - obs||^2
+//   depth  = P.z, what HasPointPositiveDepth (base/projection.cc) tests against eps
+//            (base/reconstruction.cc:837-855 FilterObservationsWithNegativeDepth)
+void oracle_ba_observation_errors(const oracle_ba_problem* p, double* sq_err, double* depth) {
+  for (int64_t o = 0; o < p->num_obs; ++o) {
+    const int im = p->obs_image[o], pt = p->obs_point[o], cm = p->image_camera[im];
+    const double* pose = p->poses + 7 * (size_t)im;
+    const double* X = p->points + 3 * (size_t)pt;
+    double q[4] = {pose[0], pose[1], pose[2], pose[3]};
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n == 0) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+    else for (double& v : q) v /= n;
+    double P[3];
+    unit_quaternion_rotate_point(q, X, P);
+    for (int k = 0; k < 3; ++k) P[k] += pose[4 + k];
+    if (depth) depth[o] = P[2];
+    if (!sq_err) continue;
+    if (P[2] < std::numeric_limits<double>::epsilon()) { sq_err[o] = std::numeric_limits<double>::max(); continue; }
+    double x, y;
+    world_to_image<double>(p->cam_model[cm], p->cam_params + p->cam_param_off[cm], P[0] / P[2], P[1] / P[2], &x, &y);
+    const double dx = x - p->obs_xy[2 * o], dy = y - p->obs_xy[2 * o + 1];
+    sq_err[o] = dx * dx + dy * dy;
+  }
+}
+
 // Cost 1/2 sum rho(||r_block||^2) plus loss-corrected, manifold-projected
 // normal-equation blocks:
 //   Himg [I][6][6], gimg [I][6]   pose tangent = (3 quaternion-tangent, 3 tvec); zero for constant poses

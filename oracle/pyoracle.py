@@ -199,6 +199,18 @@ def associate(X, out6, ok, max_range, gate_mode):
     return abcd, typ, dist, ang, d2p
 
 
+def filter_lidar_outlier(X, lidar_xyz, typ, max_proj, max_icp):
+    X = np.ascontiguousarray(X, np.float64).reshape(-1, 3)
+    lx = np.ascontiguousarray(lidar_xyz, np.float64).reshape(-1, 3)
+    typ = np.ascontiguousarray(typ, np.uint8)
+    out = np.zeros(X.shape[0], np.uint8)
+    L = lib()
+    L.oracle_filter_lidar_outlier.restype = None
+    L.oracle_filter_lidar_outlier.argtypes = [f64p, f64p, u8p, C.c_uint64, C.c_double, C.c_double, u8p]
+    L.oracle_filter_lidar_outlier(X, lx, typ, X.shape[0], max_proj, max_icp, out)
+    return out
+
+
 def search_range_schedule(opt_num, kd_max=1.5, kd_min=0.2, drop=0.1):
     opt_num = np.ascontiguousarray(opt_num, np.int32)
     out = np.empty(opt_num.shape[0], np.float64)
@@ -294,6 +306,16 @@ class BA:
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         lib().oracle_ba_evaluate_raw(C.byref(self._p), vp(res), vp(Jq), vp(Jt), vp(JX), vp(Jc), vp(JL))
         return res, Jq, Jt, JX, Jc, JL
+
+    def observation_errors(self):
+        O = len(self.obs_image)
+        sq = np.zeros(O)
+        depth = np.zeros(O)
+        L = lib()
+        L.oracle_ba_observation_errors.restype = None
+        L.oracle_ba_observation_errors.argtypes = [C.POINTER(BAProblem), C.c_void_p, C.c_void_p]
+        L.oracle_ba_observation_errors(C.byref(self._p), sq.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p))
+        return sq, depth
 
     def normal_equations(self, want_w=False):
         I, P, O = self.poses.shape[0], self.points.shape[0], len(self.obs_image)
