@@ -91,7 +91,21 @@ ABI_SYMBOLS = [
     "pcd_profile_enable", "pcd_profile_reset", "pcd_profile_get", "pcd_nn_last_stats",
     "pcd_sift_match", "pcd_sift_match_device",
     "pcd_filter_lidar_outlier_device", "pcd_ba_observation_errors", "pcd_ba_observation_errors_device",
+    "pcd_proj_default_options", "pcd_proj_create", "pcd_proj_destroy", "pcd_proj_num_submaps",
+    "pcd_proj_last_pairs", "pcd_proj_scale_coeffs", "pcd_proj_set_new_images",
 ]
+
+
+class ProjOptions(C.Structure):
+    """lidar/pcd_projection.h:31-47 (numeric members)."""
+    _fields_ = [("depth_image_scale", C.c_double), ("max_proj_scale", C.c_int32), ("min_proj_scale", C.c_int32),
+                ("min_proj_dist", C.c_double), ("submap_length", C.c_float), ("submap_width", C.c_float),
+                ("submap_height", C.c_float), ("choose_meter", C.c_float), ("min_lidar_proj_dist", C.c_double)]
+
+
+class ProjImage(C.Structure):
+    _fields_ = [("qvec", C.c_double * 4), ("tvec", C.c_double * 3), ("params", C.c_double * 8),
+                ("width", C.c_uint64), ("height", C.c_uint64), ("feat_begin", C.c_uint64), ("feat_end", C.c_uint64)]
 
 _LIB = None
 
@@ -308,6 +322,78 @@ def filter_lidar_outlier_device(d_points, d_lidar_xyz, d_type, n, max_proj, max_
                                                   C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     _check(L.pcd_filter_lidar_outlier_device(device, _ptr(d_points), _ptr(d_lidar_xyz), _ptr(d_type), n, max_proj,
                                              max_icp, _ptr(d_erase), C.c_void_p(stream)))
+
+
+class Projector:
+    """Depth-projection association over a Cloud (reference: lidar::PcdProj, lidar/pcd_projection.h:48-185)."""
+
+    def __init__(self, cloud, options=None, **kw):
+        L = lib()
+        L.pcd_proj_create.argtypes = [C.c_void_p, C.POINTER(ProjOptions), C.POINTER(C.c_void_p)]
+        L.pcd_proj_destroy.argtypes = [C.c_void_p]
+        L.pcd_proj_destroy.restype = None
+        L.pcd_proj_num_submaps.argtypes = [C.c_void_p]
+        L.pcd_proj_num_submaps.restype = C.c_uint64
+        L.pcd_proj_last_pairs.argtypes = [C.c_void_p]
+        L.pcd_proj_last_pairs.restype = C.c_uint64
+        L.pcd_proj_scale_coeffs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.pcd_proj_set_new_images.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(ProjImage), C.c_uint64] + \
+            [C.c_void_p] * 6
+        if options is None:
+            options = ProjOptions()
+            L.pcd_proj_default_options(C.byref(options))
+        for k, v in kw.items():
+            setattr(options, k, v)
+        self.options = options
+        self._cloud = cloud          # keep the cloud alive
+        self._h = None
+        h = C.c_void_p()
+        _check(L.pcd_proj_create(cloud._h, C.byref(options), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().pcd_proj_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_submaps(self):
+        return int(lib().pcd_proj_num_submaps(self._h))
+
+    @property
+    def last_pairs(self):
+        return int(lib().pcd_proj_last_pairs(self._h))
+
+    def scale_coeffs(self, set_to=None):
+        c4 = np.zeros(4, np.float64) if set_to is None else np.ascontiguousarray(set_to, np.float64)
+        latched = C.c_int(0)
+        _check(lib().pcd_proj_scale_coeffs(self._h, 0 if set_to is None else 1, _vp(c4), C.byref(latched)))
+        return c4, bool(latched.value)
+
+    def set_new_images(self, images, feat_xy):
+        """images: list of dict(qvec, tvec, params[8], width, height, feat_begin, feat_end).
+        Returns found, lidar_index, dist, lidar6, cam_xyz."""
+        feat_xy = np.ascontiguousarray(feat_xy, np.float64).reshape(-1, 2)
+        nf = feat_xy.shape[0]
+        arr = (ProjImage * max(len(images), 1))()
+        for k, im in enumerate(images):
+            arr[k] = ProjImage((C.c_double * 4)(*im["qvec"]), (C.c_double * 3)(*im["tvec"]),
+                               (C.c_double * 8)(*im["params"]), im["width"], im["height"], im["feat_begin"],
+                               im["feat_end"])
+        found = np.zeros(nf, np.uint8)
+        index = np.zeros(nf, np.uint32)
+        dist = np.zeros(nf, np.float32)
+        l6 = np.zeros((nf, 6), np.float64)
+        cam = np.zeros((nf, 3), np.float64)
+        _check(lib().pcd_proj_set_new_images(self._h, len(images), arr, nf, _vp(feat_xy), _vp(found), _vp(index),
+                                             _vp(dist), _vp(l6), _vp(cam)))
+        return found, index, dist, l6, cam
 
 
 def search_range_schedule(opt_num, kd_max=1.5, kd_min=0.2, drop=0.1):

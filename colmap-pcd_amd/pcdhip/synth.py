@@ -186,3 +186,38 @@ def ba_scene(num_cams, num_points, seed=11, mean_extra=4.0, lidar_frac=0.9, cons
                 image_camera=np.zeros(num_cams, np.int32), points=points, obs_image=obs_image,
                 obs_point=obs_point, obs_xy=obs_xy, lidar_point=lidar_point, lidar_abcd=abcd,
                 lidar_weight=weight, image_const_pose=const_pose)
+
+
+# ------------------------------------------------------ depth projection ---
+def proj_scene(num_images, feats_per_image, seed=3, scene_box=BOX, width=4032, height=3024, params=None,
+               oob_frac=0.05):
+    """Cameras inside the cloud box with random yaw / small pitch+roll (quaternions deliberately left a little
+    un-normalised, the reference uses them as they are), OPENCV intrinsics, feature pixels U(image) with a few
+    outside the image.  Returns (images, feat_xy) in the layout of pcdhip.Projector.set_new_images."""
+    rng = np.random.default_rng(seed)
+    params = list(OPENCV_PARAMS if params is None else params)
+    images, feats = [], []
+    pos = 0
+    for i in range(num_images):
+        yaw, pitch, roll = rng.uniform(0, 2 * np.pi), rng.normal(0, 0.1), rng.normal(0, 0.05)
+        cy_, sy_ = np.cos(yaw), np.sin(yaw)
+        cp, sp = np.cos(pitch), np.sin(pitch)
+        cr, sr = np.cos(roll), np.sin(roll)
+        Ry = np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])
+        Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+        R_wc = Ry @ Rx @ Rz
+        C_w = np.array([rng.uniform(10, scene_box[0] - 10), scene_box[1] * rng.uniform(0.3, 0.7),
+                        rng.uniform(10, scene_box[2] - 10)])
+        R = R_wc.T
+        q = _quat_from_R(R) * (1.0 + rng.normal(0, 1e-3))
+        t = -R @ C_w
+        n = feats_per_image
+        xy = np.stack([rng.uniform(0, width, n), rng.uniform(0, height, n)], axis=1)
+        oob = rng.random(n) < oob_frac
+        xy[oob] += rng.choice([-1.0, 1.0], (int(oob.sum()), 2)) * np.array([width, height]) * rng.uniform(0.0, 1.2)
+        images.append(dict(qvec=q.tolist(), tvec=t.tolist(), params=params, width=width, height=height,
+                           feat_begin=pos, feat_end=pos + n))
+        feats.append(xy)
+        pos += n
+    return images, (np.concatenate(feats) if feats else np.zeros((0, 2)))

@@ -34,6 +34,7 @@ const point3D_t kInvalidPoint3DId = ~0ull;
 struct Camera {
   int model_id = 0;
   std::vector<double> params;
+  size_t width = 0, height = 0;
 };
 struct Point2D {
   double xy[2] = {0, 0};

@@ -1,7 +1,7 @@
 // lidar_hip.h -- C++ adapters with the reference's own call-site signatures on top of the C ABI.
 //
 // Mirrors (names, argument meaning, error behaviour) of:
-//   colmap::lidar::PointCloudProcess   src/lidar/ply.h:13-40   (Initialize, SearchNearestNeiborByKdtree)
+//   colmap::lidar::PointCloudProcess   src/lidar/ply.h:13-40   (Initialize, SearchNearestNeiborByKdtree, pcd_proj_)
 //   colmap::LidarPoint                 src/lidar/lidar_point.h:10-50
 //   BundleAdjustmentConfig::MatchClosestLidarPoint          src/optim/bundle_adjustment.cc:358-410
 //   the association loops of IncrementalMapper::AdjustGlobalBundleByLidar (sfm/incremental_mapper.cc:1413-1469)
@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/pcdhip.h"
+#include "pcd_proj_hip.h"
 #include "ply_reader.h"
 
 namespace colmap_hip {
@@ -54,7 +55,10 @@ inline void vset(std::array<T, N>& v, int i, double x) { v[i] = x; }
 class PointCloudProcess {
  public:
   explicit PointCloudProcess(const std::string& path = "", int device = 0) : path_(path), device_(device) {}
-  ~PointCloudProcess() { pcd_cloud_destroy(cloud_); }
+  ~PointCloudProcess() {
+    pcd_proj_.reset();   // the projector refers to the cloud
+    pcd_cloud_destroy(cloud_);
+  }
   PointCloudProcess(const PointCloudProcess&) = delete;
   PointCloudProcess& operator=(const PointCloudProcess&) = delete;
 
@@ -65,6 +69,16 @@ class PointCloudProcess {
     if (!ReadPlyXYZNormal(path_, &xyz, &nrm)) return false;
     return InitializeFromRawCloud(xyz.data(), nrm.data(), xyz.size() / 3);
   }
+  // lidar/ply.cc:9-31 with its own signature: also creates pcd_proj_ and builds its submaps (ply.cc:10, 27)
+  bool Initialize(const PcdProjectionOptions& pp_options) {
+    if (!Initialize()) return false;
+    return BuildProjector(pp_options);
+  }
+  bool BuildProjector(const PcdProjectionOptions& pp_options) {
+    pcd_proj_ = std::make_shared<PcdProj>(pp_options);
+    return cloud_ && pcd_proj_->BuildSubMap(cloud_);
+  }
+  std::shared_ptr<PcdProj> pcd_proj_;   // public member as in lidar/ply.h:33; declared before cloud_ is destroyed
 
   // lidar/ply.cc:9-31 after pcl::io::loadPLYFile: rows as stored in the PLY (LiDAR frame, lidarpt::Point
   // AoS 32 B or two arrays).  Applies the axis swap + NaN filter of ply.cc:33-57 and builds the index.
@@ -75,6 +89,7 @@ class PointCloudProcess {
     o.device = device_;
     o.layout = aos32 ? PCD_LAYOUT_AOS32 : PCD_LAYOUT_XYZ_NRM;
     o.raw_lidar_frame = 1;
+    pcd_proj_.reset();
     pcd_cloud_destroy(cloud_);
     cloud_ = nullptr;
     return pcd_cloud_create(xyz, nrm, n, &o, &cloud_) == PCD_OK;

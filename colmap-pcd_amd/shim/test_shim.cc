@@ -204,6 +204,52 @@ static void TestPlyReader() {
   CHECK(!ReadPlyXYZNormal("/tmp/pcdhip_does_not_exist.ply", &a, &b));   // load failure -> false (ply.cc:14-17)
 }
 
+// PcdProj mirror: wall z = 10 m in front of a camera at the origin (pinhole 3039 px, 4032 x 3024)
+static int TestGpuProjection() {
+  std::vector<float> xyz, nrm;
+  for (int i = -100; i <= 100; ++i)
+    for (int j = -60; j <= 60; ++j) {
+      const float vx = 0.05f * i, vy = 0.05f * j, vz = 10.0f;         // visual frame
+      xyz.insert(xyz.end(), {vz, -vx, -vy});
+      nrm.insert(nrm.end(), {-1.f, 0.f, 0.f});                         // visual normal (0,0,-1)
+    }
+  lidar::PointCloudProcess pcp;
+  CHECK(pcp.InitializeFromRawCloud(xyz.data(), nrm.data(), xyz.size() / 3));
+  lidar::PcdProjectionOptions pp;
+  pp.min_lidar_proj_dist = 0.5;
+  CHECK(pcp.BuildProjector(pp));
+  CHECK(pcd_proj_num_submaps(pcp.pcd_proj_->handle()) > 0);
+  Camera cam;
+  cam.model_id = 4;
+  cam.params = {3039, 3039, 2016, 1512, 0, 0, 0, 0};
+  cam.width = 4032; cam.height = 3024;
+  Image img;
+  auto add = [&](double u, double v, point3D_t id) { Point2D p; p.xy[0] = u; p.xy[1] = v; p.point3D_id = id; img.points2D.push_back(p); };
+  add(2016, 1512, 11);            // centre: hits the wall
+  add(2016 + 1000, 1512, 12);     // 3.29 m to the right at 10 m: still on the wall (|x| <= 5)
+  add(2016 + 1900, 1512, 13);     // 6.25 m: beyond the wall's edge (and beyond any splat)
+  add(100, 100, kInvalidPoint3DId);   // no 3D point: not a feature of overload #1
+  add(2016, 1512, 14);
+  std::map<uint64_t, lidar::PcdProj::Vector6> map;
+  pcp.pcd_proj_->SetNewImage(img, cam, map);
+  CHECK_EQ(map.size(), 3u);
+  CHECK(map.count(11) && map.count(12) && map.count(14) && !map.count(13));
+  CHECK(map[11][2] == 10.0 && map[11][5] == -1.0 && std::fabs(map[11][0]) < 0.5);
+  CHECK(map[11] == map[14]);
+  CHECK(std::fabs(map[12][0] - 3.29) < 0.5);
+  // overload #2: every pt_xy, plane/ray intersection in the camera frame
+  std::vector<std::pair<std::array<double, 2>, bool>> pt_xys = {{{2016, 1512}, false}, {{3016, 1512}, false},
+                                                                {{3916, 1512}, true}, {{-50, 10}, true}};
+  std::vector<std::array<double, 3>> pt_xyzs;
+  pcp.pcd_proj_->SetNewImage(img, cam, pt_xys, pt_xyzs);
+  CHECK_EQ(pt_xyzs.size(), 4u);
+  CHECK(pt_xys[0].second && pt_xys[1].second && !pt_xys[2].second && !pt_xys[3].second);
+  CHECK(pt_xyzs[0][2] == 10.0 && pt_xyzs[0][0] == 0.0);
+  CHECK(std::fabs(pt_xyzs[1][0] - 10.0 * 1000 / 3039) < 1e-12 && pt_xyzs[1][2] == 10.0);
+  CHECK(pt_xyzs[2][0] == 0.0 && pt_xyzs[2][2] == 0.0 && pt_xyzs[3][2] == 0.0);
+  return 0;
+}
+
 static int TestGpu() {
   if (pcd_device_count() < 1) { std::printf("FAIL: --gpu given but no gfx950 device\n"); return 1; }
   // cloud: plane y = 1 (visual frame) on a 5 cm lattice with normal (0,1,0), given in the raw LiDAR frame
@@ -270,7 +316,7 @@ static int TestGpu() {
   for (double r : res) s += r * r;
   CHECK(std::fabs(cost - 0.5 * s) <= 1e-9 * cost);
   CHECK(cost > 0 && cost < 300 * 8.0 + 1e4);   // +-2 px noise on 300 observations + one lidar term
-  return 0;
+  return TestGpuProjection();
 }
 
 int main(int argc, char** argv) {

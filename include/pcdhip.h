@@ -172,10 +172,60 @@ pcd_status pcd_associate_from_payload_device(int device, const double* d_q_xyz, 
  *   Reconstruction::FilterLidarOutlier: erase[i] = 1 when ||lidar_xyz[i] - points_xyz[i]|| exceeds
  *   max_proj_dist_error (type PCD_LIDAR_PROJ) or max_icp_dist_error (Icp / IcpGround); type 0 rows are
  *   left alone.  Device pointers (the arrays normally still live in HBM after BA). */
-#define PCD_LIDAR_PROJ 3   /* LidarPointType::Proj: depth-projection associations (not produced here yet) */
+#define PCD_LIDAR_PROJ 3   /* LidarPointType::Proj: depth-projection associations (pcd_proj_*) */
 pcd_status pcd_filter_lidar_outlier_device(int device, const double* d_points_xyz, const double* d_lidar_xyz,
                                            const uint8_t* d_type, uint64_t n, double max_proj_dist_error,
                                            double max_icp_dist_error, uint8_t* d_erase, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Depth-projection association (LidarPointType::Proj)   replaces lidar/pcd_projection.{h,cc} `PcdProj`
+ *   pcd_proj_create          <- PcdProj::PcdProj + BuildSubMap          pcd_projection.h:52, .cc:223-255
+ *   pcd_proj_set_new_images  <- both PcdProj::SetNewImage overloads     .cc:13-89, .cc:102-220
+ *                               (SearchSubMap .cc:258-297, SearchImageMap .cc:499-559,
+ *                                ImageMapProj .cc:305-468, DistortOpenCV .cc:561-594), for a batch of images.
+ * The winner of a feature pixel is the LiDAR point with the smallest float camera-frame norm among the points
+ * whose splat covers the pixel; equal norms resolve to the point the reference's single-thread walk meets first
+ * (submap key order, then cloud row) -- the reference's OpenMP loop is racy there, this is deterministic.
+ * The cloud handle must outlive the projector and must hold the whole cloud (no shard).
+ * --------------------------------------------------------------------- */
+typedef struct pcd_proj pcd_proj;
+typedef struct {                 /* lidar/pcd_projection.h:31-47, numeric members */
+  double depth_image_scale;      /* 0.2 */
+  int32_t max_proj_scale;        /* 10  */
+  int32_t min_proj_scale;        /* 2   */
+  double min_proj_dist;          /* 2   */
+  float submap_length;           /* x, 1.0 */
+  float submap_width;            /* z, 1.0 */
+  float submap_height;           /* y, 1.0 */
+  float choose_meter;            /* 40  */
+  double min_lidar_proj_dist;    /* no default in the reference; controllers/incremental_mapper.cc:345 */
+} pcd_proj_options;
+typedef struct {
+  double qvec[4], tvec[3];       /* Image::Qvec (w,x,y,z; used un-normalised as the reference does), Tvec */
+  double params[8];              /* fx fy cx cy k1 k2 p1 p2: the reference reads an OPENCV camera
+                                    unconditionally (.cc:21, .cc:561-571); zero-fill what a model lacks */
+  uint64_t width, height;        /* Camera::Width / Height (full resolution) */
+  uint64_t feat_begin, feat_end; /* this image's rows of feat_xy */
+} pcd_proj_image;
+void pcd_proj_default_options(pcd_proj_options* o);
+pcd_status pcd_proj_create(pcd_cloud* cloud, const pcd_proj_options* options, pcd_proj** out);
+void pcd_proj_destroy(pcd_proj* p);
+uint64_t pcd_proj_num_submaps(const pcd_proj* p);
+uint64_t pcd_proj_last_pairs(const pcd_proj* p);   /* (image, submap) pairs the last call projected */
+/* The splat half-width beyond min_proj_dist is a_x*depth+b_x (and y): four function-local `static`s in the
+ * reference (.cc:391-397), initialised from the FIRST camera the process projects with and never again.
+ * Here they latch per projector on the first image of the first call; set=1 overrides them (coeffs4 = a_x, b_x,
+ * a_y, b_y), set=0 reads them back.  *latched (optional) reports whether they are fixed yet. */
+pcd_status pcd_proj_scale_coeffs(pcd_proj* p, int set, double* coeffs4, int* latched);
+/* Host buffers.  feat_xy: [n_feat][2] full-resolution pixel coordinates (for overload #1 pass the Point2D's that
+ * have a 3D point; for #2 every pt_xy).  Any output may be NULL:
+ *   found[n_feat]        1 when a LiDAR point was matched (pt_xy.second of overload #2)
+ *   lidar_index[n_feat]  cloud row of the winner (0xFFFFFFFF when none), dist[n_feat] its float norm
+ *   lidar6[n_feat][6]    overload #1 value: x y z nx ny nz as doubles (zeros when none)
+ *   cam_xyz[n_feat][3]   overload #2 value: pixel ray intersected with the winner's plane (zeros when none) */
+pcd_status pcd_proj_set_new_images(pcd_proj* p, uint64_t n_images, const pcd_proj_image* images, uint64_t n_feat,
+                                   const double* feat_xy, uint8_t* found, uint32_t* lidar_index, float* dist,
+                                   double* lidar6, double* cam_xyz);
 
 /* search-radius schedule, sfm/incremental_mapper.cc:1159-1163, 1423-1427 */
 pcd_status pcd_search_range_schedule(const int32_t* global_opt_num, uint64_t n, double kd_max,

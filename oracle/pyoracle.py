@@ -324,3 +324,71 @@ class BA:
         vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
         cost = lib().oracle_ba_normal_equations(C.byref(self._p), vp(Himg), vp(gimg), vp(Hpt), vp(gpt), vp(W))
         return cost, Himg, gimg, Hpt, gpt, W
+
+
+# ------------------------------------------------- depth projection (N1) ----
+class ProjOptions(C.Structure):
+    """lidar/pcd_projection.h:31-47 (the numeric members)."""
+    _fields_ = [("depth_image_scale", C.c_double), ("max_proj_scale", C.c_int32), ("min_proj_scale", C.c_int32),
+                ("min_proj_dist", C.c_double), ("submap_length", C.c_float), ("submap_width", C.c_float),
+                ("submap_height", C.c_float), ("choose_meter", C.c_float), ("min_lidar_proj_dist", C.c_double)]
+
+
+class ProjImage(C.Structure):
+    _fields_ = [("qvec", C.c_double * 4), ("tvec", C.c_double * 3), ("params", C.c_double * 8),
+                ("width", C.c_uint64), ("height", C.c_uint64), ("feat_begin", C.c_uint64), ("feat_end", C.c_uint64)]
+
+
+def proj_options(depth_image_scale=0.2, max_proj_scale=10, min_proj_scale=2, min_proj_dist=2.0, submap=1.0,
+                 choose_meter=40.0, min_lidar_proj_dist=0.5):
+    return ProjOptions(depth_image_scale, max_proj_scale, min_proj_scale, min_proj_dist, submap, submap, submap,
+                       choose_meter, min_lidar_proj_dist)
+
+
+def proj_scale_coeffs(opt, fx, fy):
+    c4 = np.zeros(4, np.float64)
+    L = lib()
+    L.oracle_proj_scale_coeffs.restype = None
+    L.oracle_proj_scale_coeffs.argtypes = [C.POINTER(ProjOptions), C.c_double, C.c_double, f64p]
+    L.oracle_proj_scale_coeffs(C.byref(opt), fx, fy, c4)
+    return c4
+
+
+def proj_images(xyz, nrm, opt, coeffs, images, feat_xy):
+    """images: list of dict(qvec, tvec, params[8], width, height, feat_begin, feat_end).
+    Returns found, index, dist, lidar6, cam_xyz (SetNewImage #1 and #2 outputs), pairs."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    nrm = np.ascontiguousarray(nrm, np.float32).reshape(-1, 3)
+    feat_xy = np.ascontiguousarray(feat_xy, np.float64).reshape(-1, 2)
+    nf = feat_xy.shape[0]
+    arr = (ProjImage * len(images))()
+    for k, im in enumerate(images):
+        arr[k] = ProjImage((C.c_double * 4)(*im["qvec"]), (C.c_double * 3)(*im["tvec"]),
+                           (C.c_double * 8)(*im["params"]), im["width"], im["height"], im["feat_begin"],
+                           im["feat_end"])
+    found = np.zeros(nf, np.uint8)
+    index = np.full(nf, 0xFFFFFFFF, np.uint32)      # rows that belong to no image stay "none"
+    dist = np.zeros(nf, np.float32)
+    L = lib()
+    L.oracle_proj_images.restype = C.c_int64
+    L.oracle_proj_images.argtypes = [f32p, C.c_uint64, C.POINTER(ProjOptions), f64p, C.c_uint64,
+                                     C.POINTER(ProjImage), f64p, u8p, u32p, f32p]
+    pairs = L.oracle_proj_images(xyz, xyz.shape[0], C.byref(opt), np.ascontiguousarray(coeffs, np.float64),
+                                 len(images), arr, feat_xy, found, index, dist)
+    assert pairs >= 0
+    l6 = np.zeros((nf, 6), np.float64)
+    L.oracle_proj_lidar6.restype = None
+    L.oracle_proj_lidar6.argtypes = [f32p, f32p, C.c_uint64, u8p, u32p, f64p]
+    L.oracle_proj_lidar6(xyz, nrm, nf, found, index, l6)
+    cam = np.zeros((nf, 3), np.float64)
+    L.oracle_proj_ray_plane.restype = None
+    L.oracle_proj_ray_plane.argtypes = [f64p, C.c_uint64, f64p, u8p, f64p, f64p]
+    for im in images:
+        b, e = im["feat_begin"], im["feat_end"]
+        if e > b:
+            c = np.zeros((e - b, 3), np.float64)
+            L.oracle_proj_ray_plane(np.ascontiguousarray(im["params"], np.float64), e - b,
+                                    np.ascontiguousarray(feat_xy[b:e]), np.ascontiguousarray(found[b:e]),
+                                    np.ascontiguousarray(l6[b:e]), c)
+            cam[b:e] = c
+    return found, index, dist, l6, cam, pairs
