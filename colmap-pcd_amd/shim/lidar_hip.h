@@ -11,6 +11,7 @@
 // Header-only; link with -lpcdhip.  No CPU fallback: every call fails (returns false) without a gfx950 device.
 #pragma once
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -51,7 +52,7 @@ inline void vset(V& v, int i, double x) { v(i) = x; }
 template <typename T, size_t N>
 inline void vset(std::array<T, N>& v, int i, double x) { v[i] = x; }
 
-// Replaces lidar::PointCloudProcess for the KD-tree side (the depth-projection side, pcd_proj_, is untouched).
+// Replaces lidar::PointCloudProcess: the KD-tree side (cloud_) and the depth-projection side (pcd_proj_).
 class PointCloudProcess {
  public:
   explicit PointCloudProcess(const std::string& path = "", int device = 0) : path_(path), device_(device) {}
@@ -175,6 +176,49 @@ inline bool MatchClosestLidarPoints(lidar::PointCloudProcess& pcp, const std::ve
     lp.angle = angle[i];
     (*lidar_maps)[point3D_ids[i]] = lp;
   }
+  return true;
+}
+
+// BundleAdjustmentConfig::MatchVariablePoint2LidarPoint (optim/bundle_adjustment.cc:288-350): among the images
+// of the point's track that were projected (PcdProj::SetNewImage(s) -> searched[image_id]), take the candidate
+// whose |cos| between (X - lidar point) and the lidar normal is smallest (strict <, track order), and record it
+// as a LidarPointType::Proj association: plane normalised (lidar_point.cc:39-50), dist = point-to-PLANE distance
+// (lidar_point.cc:21-25; the KD-tree paths store point-to-point instead), angle (lidar_point.cc:32-37), red.
+// Host code on a handful of candidates per point, like the reference.  Returns false when no image has one.
+template <typename SearchedMap, typename TrackImageIds>
+inline bool MatchVariablePoint2LidarPoint(const SearchedMap& searched, uint64_t point3D_id, const double* X,
+                                          const TrackImageIds& track_image_ids, LidarPoint* out) {
+  double angle = 360;
+  std::array<double, 6> best{};
+  for (const auto image_id : track_image_ids) {
+    const auto it = searched.find(image_id);
+    if (it == searched.end()) continue;
+    const auto lp = it->second.find(point3D_id);
+    if (lp == it->second.end()) continue;
+    const std::array<double, 6>& c = lp->second;
+    const double v[3] = {X[0] - c[0], X[1] - c[1], X[2] - c[2]};
+    const double dot = v[0] * c[3] + v[1] * c[4] + v[2] * c[5];
+    const double nn = std::sqrt(c[3] * c[3] + c[4] * c[4] + c[5] * c[5]);
+    const double vn = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double a = std::fabs(dot / (nn * vn));
+    if (a < angle) {   // NaN (zero normal / X on the lidar point) never wins, as in the reference
+      angle = a;
+      best = c;
+    }
+  }
+  if (angle == 360) return false;
+  LidarPoint p;
+  p.type = LidarPointType::Proj;
+  for (int k = 0; k < 3; ++k) p.xyz[k] = best[k];
+  const double norm = std::sqrt(std::pow(best[3], 2) + std::pow(best[4], 2) + std::pow(best[5], 2));
+  const double a = best[3] / norm, b = best[4] / norm, c = best[5] / norm;
+  const double d = 0 - a * p.xyz[0] - b * p.xyz[1] - c * p.xyz[2];
+  p.abcd = {a, b, c, d};
+  p.dist = std::fabs((X[0] * a + X[1] * b + X[2] * c) + d);
+  const double w[3] = {X[0] - p.xyz[0], X[1] - p.xyz[1], X[2] - p.xyz[2]};
+  p.angle = std::fabs((a * w[0] + b * w[1] + c * w[2]) / std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]));
+  p.color = {255, 0, 0};
+  *out = p;
   return true;
 }
 

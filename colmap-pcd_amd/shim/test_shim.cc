@@ -182,6 +182,27 @@ static std::string WritePly(bool binary, bool short_names, const std::vector<flo
   return path;
 }
 
+// MatchVariablePoint2LidarPoint (optim/bundle_adjustment.cc:288-350) on hand-computed candidates
+static void TestMatchVariablePoint() {
+  std::map<uint32_t, std::map<uint64_t, std::array<double, 6>>> searched;
+  const double X[3] = {1.0, 2.0, 3.0};
+  // image 5: lidar point straight below X along its normal -> |cos| = 1;  image 6: offset sideways -> smaller |cos|
+  searched[5][42] = {1.0, 2.0, 2.5, 0, 0, 2.0};
+  searched[6][42] = {0.0, 2.0, 2.5, 0, 0, -4.0};
+  searched[7][99] = {9, 9, 9, 1, 0, 0};                 // other point only
+  std::vector<uint32_t> track = {5, 7, 6, 8};
+  LidarPoint lp;
+  CHECK(MatchVariablePoint2LidarPoint(searched, 42, X, track, &lp));
+  CHECK(lp.type == LidarPointType::Proj && lp.color[0] == 255 && lp.color[1] == 0);
+  CHECK(lp.xyz[0] == 0.0 && lp.xyz[2] == 2.5);                       // image 6 wins: cos = 0.5/sqrt(1.25) < 1
+  CHECK(lp.abcd[2] == -1.0 && lp.abcd[3] == 2.5);                    // normalised plane z = 2.5
+  CHECK(std::fabs(lp.dist - 0.5) < 1e-15);                           // point-to-plane
+  CHECK(std::fabs(lp.angle - 0.5 / std::sqrt(1.25)) < 1e-15);
+  CHECK(!MatchVariablePoint2LidarPoint(searched, 43, X, track, &lp));
+  std::vector<uint32_t> only5 = {5};
+  CHECK(MatchVariablePoint2LidarPoint(searched, 42, X, only5, &lp) && lp.xyz[0] == 1.0 && lp.angle == 1.0);
+}
+
 static void TestPlyReader() {
   std::vector<float> xyz, nrm;
   std::mt19937 rng(3);
@@ -326,6 +347,7 @@ int main(int argc, char** argv) {
   TestForceToOptimizePoint();
   TestLidarBlocks();
   TestPlyReader();
+  TestMatchVariablePoint();
   if (argc > 1 && std::strcmp(argv[1], "--gpu") == 0) g_fail += TestGpu();
   std::printf(g_fail ? "%d FAILED\n" : "ALL OK\n", g_fail);
   return g_fail ? 1 : 0;
