@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <numeric>
 
+#include "ba_cam_jac.h"
 #include "ba_math.h"
 #include "common.h"
 
@@ -258,6 +259,34 @@ __global__ __launch_bounds__(256) void k_ba_raw(BaDev d, double* __restrict__ re
   }
 }
 
+// Camera-parameter block of every reprojection residual (2 x K, row stride PCD_CAM_JAC_STRIDE).
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_ba_cam_jac(BaDev d, double* __restrict__ Jc_o) {
+  const uint64_t o = blockIdx.x * (uint64_t)256 + threadIdx.x;
+  if (o >= d.O) return;
+  const int im = d.obs_image[o], pt = d.obs_point[o];
+  const double* pose = d.poses + 7 * (size_t)im;
+  const double* Xp = d.points + 3 * (size_t)pt;
+  const double X[3] = {Xp[0], Xp[1], Xp[2]};
+  const double w = pose[0], a = pose[1], bq = pose[2], c = pose[3];
+  // same rotation polynomial as reproj_eval
+  const double cx = bq * X[2] - c * X[1], cy = c * X[0] - a * X[2], cz = a * X[1] - bq * X[0];
+  const double ux = 2.0 * cx, uy = 2.0 * cy, uz = 2.0 * cz;
+  const double Px = X[0] + w * ux + (bq * uz - c * uy) + pose[4];
+  const double Py = X[1] + w * uy + (c * ux - a * uz) + pose[5];
+  const double Pz = X[2] + w * uz + (a * uy - bq * ux) + pose[6];
+  const double iz = 1.0 / Pz;
+  const int cm = d.image_cam[im];
+  double J[2 * PCD_CAM_JAC_STRIDE];
+#pragma unroll
+  for (int k = 0; k < 2 * PCD_CAM_JAC_STRIDE; ++k) J[k] = 0.0;
+  if (MODEL >= 0) cam_param_jacobian<(MODEL >= 0 ? MODEL : 0)>(d.cam_params + d.cam_off[cm], Px * iz, Py * iz, J, PCD_CAM_JAC_STRIDE);
+  else cam_param_jacobian_any(d.cam_model[cm], d.cam_params + d.cam_off[cm], Px * iz, Py * iz, J, PCD_CAM_JAC_STRIDE);
+  double* out = Jc_o + 2 * PCD_CAM_JAC_STRIDE * o;
+#pragma unroll
+  for (int k = 0; k < 2 * PCD_CAM_JAC_STRIDE; ++k) out[k] = J[k];
+}
+
 // Inputs of the post-BA filters, per observation:
 //   sq_err = CalculateSquaredReprojectionError (base/projection.cc:104-117; quaternion normalised first as
 //            base/pose.cc QuaternionRotatePoint does; DBL_MAX when the point is not in front of the camera)
@@ -319,7 +348,7 @@ struct pcd_ba {
   DevBuf<uint32_t> slice_start, pt_lidar_start, pt_lidar_list, img_obs_start;
   DevBuf<double> cost_partial, cost;
   // host-API staging
-  DevBuf<double> o_res, o_jq, o_jt, o_jx, o_jl, o_himg, o_gimg, o_hpt, o_gpt, o_w;
+  DevBuf<double> o_res, o_jq, o_jt, o_jx, o_jl, o_himg, o_gimg, o_hpt, o_gpt, o_w, o_jc;
   BaDev dev() const {
     BaDev d;
     d.cam_model = cam_model.p; d.cam_off = cam_off.p; d.cam_params = cam_params.p;
@@ -532,6 +561,10 @@ pcd_status pcd_ba_evaluate_device(pcd_ba* b, const pcd_ba_out* o, void* stream) 
     PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_raw<M>), dim3(div_up(b->O, 256)), dim3(256), 0, s, d, o->residuals,
                                                o->jac_q, o->jac_t, o->jac_X, o->W));
   }
+  if (o->jac_cam && b->O) {
+    ScopedKernelTimer t("ba_cam_jac", s);
+    PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_cam_jac<M>), dim3(div_up(b->O, 256)), dim3(256), 0, s, d, o->jac_cam));
+  }
   if ((o->residuals || o->jac_lidar) && b->L) {
     ScopedKernelTimer t("ba_lidar_raw", s);
     hipLaunchKernelGGL(k_ba_lidar_raw, dim3(div_up(b->L, 256)), dim3(256), 0, s, d, o->residuals, o->jac_lidar);
@@ -583,6 +616,7 @@ pcd_status pcd_ba_evaluate(pcd_ba* b, const pcd_ba_out* o) {
       {o->H_pt, &b->o_hpt, 9 * (size_t)b->P, &d.H_pt},
       {o->g_pt, &b->o_gpt, 3 * (size_t)b->P, &d.g_pt},
       {o->W, &b->o_w, 18 * b->O, &d.W},
+      {o->jac_cam, &b->o_jc, 2 * PCD_CAM_JAC_STRIDE * b->O, &d.jac_cam},
   };
   for (auto& it : items)
     if (it.host) {

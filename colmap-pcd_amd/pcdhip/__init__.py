@@ -64,9 +64,12 @@ class BADesc(C.Structure):
                 ("reserved", C.c_int32 * 8)]
 
 
+CAM_JAC_STRIDE = 12
+
+
 class BAOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("cost", "residuals", "jac_q", "jac_t", "jac_X", "jac_lidar",
-                                           "H_img", "g_img", "H_pt", "g_pt", "W")]
+                                           "H_img", "g_img", "H_pt", "g_pt", "W", "jac_cam")]
 
 
 class KernelTime(C.Structure):
@@ -487,7 +490,7 @@ class BA:
                              "g_pt")):
         shapes = dict(cost=(1,), residuals=(2 * self.O + self.L,), jac_q=(self.O, 2, 4), jac_t=(self.O, 2, 3),
                       jac_X=(self.O, 2, 3), jac_lidar=(self.L, 3), H_img=(self.I, 6, 6), g_img=(self.I, 6),
-                      H_pt=(self.P, 3, 3), g_pt=(self.P, 3), W=(self.O, 6, 3))
+                      H_pt=(self.P, 3, 3), g_pt=(self.P, 3), W=(self.O, 6, 3), jac_cam=(self.O, 2, CAM_JAC_STRIDE))
         out = {k: np.zeros(shapes[k]) for k in want}
         bo = BAOut(*[_vp(out.get(n)) for n, _ in BAOut._fields_])
         _check(lib().pcd_ba_evaluate(self._h, C.byref(bo)))

@@ -267,9 +267,9 @@ int pcd_camera_num_params(int model_id);   /* -1 for an unknown id */
  * image is outside the config (:967-983): such blocks use the constant-pose functor.
  * image_const_tvec[i] bit k = tvec[k] held constant (SetSubsetManifold :912-915).
  * point_const[p] = ParameterizePoints (:1107-1131).
- * Intrinsics are held constant (ba_refine_* default false,
- * controllers/incremental_mapper.h:156-158) unless camera_refine != NULL
- * (not implemented in this version: PCD_ERR_UNSUPPORTED). */
+ * Intrinsics are held constant in the normal-equation outputs (ba_refine_* default false,
+ * controllers/incremental_mapper.h:156-158); camera_refine != NULL (camera blocks in H/g) is
+ * PCD_ERR_UNSUPPORTED.  The raw path serves refined intrinsics through pcd_ba_out.jac_cam. */
 typedef struct {
   int32_t device;
   int32_t num_cameras;
@@ -311,9 +311,14 @@ pcd_status pcd_ba_set_parameters(pcd_ba* ba, const double* poses /*[I][7]*/, con
  *   residuals [2*O + L]   obs blocks first, then lidar blocks
  *   jac_q [O][2][4]  jac_t [O][2][3]  jac_X [O][2][3]   (zero rows for constant-pose blocks)
  *   jac_lidar [L][3]
+ *   jac_cam [O][2][PCD_CAM_JAC_STRIDE]   the camera-parameter block (2 x K row-major in the first K columns of
+ *             each row, K = pcd_camera_num_params(model), remaining columns zero): what autodiff returns when
+ *             refine_focal_length / refine_principal_point / refine_extra_params (optim/bundle_adjustment.h:76-81)
+ *             leave the camera block variable; Ceres applies its SubsetManifold for the constant subset itself.
  * Normal-equation blocks use the loss-corrected residuals/Jacobians projected on
  * the manifolds (pose tangent = 3 quaternion-tangent + 3 tvec):
  *   H_img [I][6][6] g_img [I][6]   H_pt [P][3][3] g_pt [P][3]   W [O][6][3] = Jp^T JX */
+#define PCD_CAM_JAC_STRIDE 12   /* widest camera model (FULL_OPENCV, THIN_PRISM_FISHEYE) */
 typedef struct {
   double* cost;        /* [1]  1/2 sum rho(||r_block||^2) */
   double* residuals;
@@ -326,6 +331,7 @@ typedef struct {
   double* H_pt;
   double* g_pt;
   double* W;
+  double* jac_cam;     /* [O][2][PCD_CAM_JAC_STRIDE] d r / d camera params, see above */
 } pcd_ba_out;
 
 pcd_status pcd_ba_evaluate(pcd_ba* ba, const pcd_ba_out* out);                 /* host outputs   */

@@ -40,8 +40,13 @@ def test_raw_blocks_all_camera_models(gpu, oracle, model):
     ob = oracle.BA(**s)
     res, Jq, Jt, JX, Jc, JL = ob.evaluate_raw()
     ba = gpu.BA(**s)
-    got = ba.evaluate(("residuals", "jac_q", "jac_t", "jac_X", "jac_lidar"))
+    got = ba.evaluate(("residuals", "jac_q", "jac_t", "jac_X", "jac_lidar", "jac_cam"))
     _close(got["residuals"], res, 1e-9, "residuals")
+    # camera-parameter block (refine_focal_length / principal_point / extra_params): 2 x K in a stride-12 row
+    K = oracle.lib().oracle_camera_num_params(model)
+    assert Jc.shape[2] >= K and np.abs(Jc[:, :, :K]).max() > 0
+    _close(got["jac_cam"][:, :, :K], Jc[:, :, :K], 1e-9, "Jc")
+    assert not got["jac_cam"][:, :, K:].any()
     _close(got["jac_q"], Jq, 1e-9, "Jq")
     _close(got["jac_t"], Jt, 1e-9, "Jt")
     _close(got["jac_X"], JX, 1e-9, "JX")
