@@ -1,8 +1,12 @@
 // brick_kernel.h -- the LDS-tiled brick kernel of the NN search (included by nn.hip).
 //
 // One wavefront per work item = (brick of B^3 cells, <= G queries whose home cell lies in it).
-// The cell rows of the brick grown by R cells are contiguous ranges of the cell-sorted cloud; their
-// concatenation is streamed through two 256-point LDS tiles per wavefront:
+// The quad rows (grid.h: 2x2 cells in (y,z), contiguous along x) of the brick grown by R cells are contiguous
+// ranges of the cell-sorted cloud -- 9 ranges for B = R = 2; their concatenation is streamed through two
+// 256-point LDS tiles per wavefront:
+//   * slot -> source address needs no search: range starts live one per lane in a VGPR, a wave-uniform cursor
+//     follows the 64-slot window of each DMA instruction and only the range boundaries inside the window
+//     (0.6 on average) cost a v_readlane + compare + select;
 //   * staging is LDS-DMA (global_load_lds_dwordx4: one 16-B record per lane, no VGPR round trip);
 //     the 4 DMAs of tile t+1 are in flight while tile t is compared (counted s_waitcnt vmcnt(4));
 //   * compare: lanes = staged points (ds_read_b128), the G queries are wave-uniform (SGPRs), every
@@ -15,6 +19,7 @@
 // A query is final when best < (distance to the staged region's boundary)^2 (nn.hip header); the
 // others go to the exact fallback with their tentative key as starting bound.
 #pragma once
+#include <type_traits>
 
 namespace pcd {
 
@@ -27,8 +32,8 @@ namespace pcd {
 #define PCD_BRICK_MINWAVES 4
 #endif
 constexpr int kTile = PCD_KTILE;
-static_assert(kTile == 128 || kTile == 192 || kTile == 256, "tile = 2, 3 or 4 DMA instructions");
-constexpr int kAblateCompare = 0x100, kAblateDma = 0x200, kAblateReduce = 0x400, kAblateFallback = 0x800;
+static_assert(kTile == 256, "a tile is 4 DMA instructions (128/192-point tiles were measured slower and removed)");
+constexpr int kAblateCompare = 0x100, kAblateDma = 0x200, kAblateReduce = 0x400, kAblateFallback = 0x800, kAblateTiles = 0x1000;
 
 __device__ __forceinline__ void lds_dma16(const float4* gsrc, float4* lds_wave_base) {
   // LDS destination = wave-uniform base + lane * 16 (hardware adds the lane offset)
@@ -111,6 +116,8 @@ __device__ __forceinline__ void brick_region(const GridParams& g, const BrickPar
   c1[2] = min(bz * b.B + b.B + b.R, g.dims[2]);
 }
 
+// Lane r < nrows gets the point range of quad row r of the region: the cells [c0,c1) of brick_region, grown in
+// y and z to whole quads (a superset; proven_bound keeps using the un-grown box, which is conservative).
 __device__ __forceinline__ BrickMeta brick_load_meta(const GridParams& g, const BrickParams& b, const uint4 it,
                                                      const float4* __restrict__ qsorted,
                                                      const uint32_t* __restrict__ cell_start) {
@@ -123,16 +130,16 @@ __device__ __forceinline__ BrickMeta brick_load_meta(const GridParams& g, const 
   m.q = qsorted[it.x + (lane < cnt ? lane : cnt - 1)];
   int c0[3], c1[3];
   brick_region(g, b, it, c0, c1);
-  const int ny = c1[1] - c0[1], nrows = ny * (c1[2] - c0[2]);  // 1 <= ny <= 8, nrows <= 64
+  const int yq0 = c0[1] >> 1, zq0 = c0[2] >> 1;
+  const int ny = ((c1[1] + 1) >> 1) - yq0, nrows = ny * (((c1[2] + 1) >> 1) - zq0);  // 1 <= ny <= 8, nrows <= 64
   const int row = lane < nrows ? lane : nrows - 1;
   // row / ny without an integer division: ceil(2^16 / ny) is exact for row < 64, ny <= 8
   const uint32_t inv = ny == 1 ? 65536u : ny == 2 ? 32768u : ny == 3 ? 21846u : ny == 4 ? 16384u
                      : ny == 5 ? 13108u : ny == 6 ? 10923u : ny == 7 ? 9363u : 8192u;
   const int rz = (int)(((uint32_t)row * inv) >> 16), ry = row - rz * ny;
-  const int cy = c0[1] + ry, cz = c0[2] + rz;
-  const uint64_t rowbase = ((uint64_t)cz * g.dims[1] + cy) * g.dims[0];
-  m.s = cell_start[rowbase + c0[0]];
-  m.e = cell_start[rowbase + c1[0]];
+  const uint64_t rowbase = quad_row_base(g, yq0 + ry, zq0 + rz);
+  m.s = cell_start[rowbase + 4 * c0[0]];
+  m.e = cell_start[rowbase + 4 * c1[0]];
   if (lane >= nrows) m.e = m.s;  // empty row
   return m;
 }
@@ -148,11 +155,7 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
   const int collect_stats = flags & 1;
   static_assert(G == 8, "the transposed reduction is written for 8 queries per group");
   __shared__ __attribute__((aligned(16))) float4 s_tile[4][2][kTile];
-  __shared__ uint32_t s_rowoff[4][kMaxRows];
-  __shared__ uint32_t s_rowsrc[4][kMaxRows];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* rowoff = s_rowoff[wave];
-  uint32_t* rowsrc = s_rowsrc[wave];
   const uint32_t nitems = ctr->nitems;
   const uint32_t nwaves = gridDim.x * 4;
   unsigned long long st_staged = 0, st_pairs = 0, st_groups = 0;
@@ -197,88 +200,116 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
     brick_region(g, b, it0, c0, c1);
     uint32_t T;
     const uint32_t len = m0.e - m0.s;
+    // lane r: start of range r in the concatenation (lanes >= nrows: T) and source - start
     const uint32_t off = wave_excl_scan_u32(len, T);
-    __builtin_amdgcn_wave_barrier();
-    rowoff[lane] = off;
-    rowsrc[lane] = m0.s;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    const uint32_t delta = m0.s - off;
 
     uint64_t best[G];
 #pragma unroll
     for (int k = 0; k < G; ++k) best[k] = kKeyInit;
 
-    if (T > 0) {
+    if (T > 0 && !(flags & kAblateTiles)) {
       const int ntiles = (int)((T + kTile - 1) / kTile);
-      // issue the 4 DMAs of tile t (always exactly 4 instructions: out-of-range lanes re-read element T-1)
-      auto issue_tile = [&](int t) {
+      // ---- slot -> source index ------------------------------------------------------------------
+      // Window w = the 64 slots of one DMA instruction.  Lane w of (w_d0, w_ob, w_d1) describes window w:
+      // the source delta at its first slot, the first range start inside it (or ~0) and the delta from
+      // there on.  Built once per item with lanes = windows: `cur` = number of range starts <= the
+      // window's first slot (the starts are non-decreasing), then three cross-lane gathers.  A window
+      // with two or more starts inside, or more than 64 windows (T > 4096), sends the whole item down
+      // the generic path below; with ~110-point ranges that is rare.
+      const uint32_t wslot = min((uint32_t)lane * 64u, T - 1);
+      uint32_t curw = 0;
+      for (int r = 1; r < 64; ++r) {
+        const uint32_t o_r = (uint32_t)__builtin_amdgcn_readlane((int)off, r);
+        if (o_r >= T) break;   // wave-uniform: lanes past the last non-empty range hold T
+        curw += o_r <= wslot ? 1u : 0u;
+      }
+      const int a1 = (int)min(curw + 1u, 63u) * 4, a2 = (int)min(curw + 2u, 63u) * 4;
+      const uint32_t w_d0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)curw * 4, (int)delta);
+      uint32_t w_ob = (uint32_t)__builtin_amdgcn_ds_bpermute(a1, (int)off);
+      const uint32_t w_d1 = (uint32_t)__builtin_amdgcn_ds_bpermute(a1, (int)delta);
+      const uint32_t w_o2 = (uint32_t)__builtin_amdgcn_ds_bpermute(a2, (int)off);
+      const bool in_use = (uint32_t)lane * 64u < T;
+      const bool two_starts = in_use && a2 != a1 && w_o2 <= wslot + 63u && w_o2 < T;
+      if (!(w_ob <= wslot + 63u && w_ob < T)) w_ob = 0xFFFFFFFFu;
+      const bool fast = __ballot(two_starts) == 0ull && T <= 4096u;
+
+      const char* __restrict__ src_bytes = reinterpret_cast<const char*>(sorted);
+      int cur = 0;   // generic path: largest range index whose start is <= the first slot of the window
+      // issue the 4 DMAs of tile t (always exactly 4 instructions: slots past T re-read point T-1, which
+      // cannot change a minimum -- the compare needs no tail mask)
+      auto issue_tile = [&](int t, auto fast_tag) {
         float4* buf = s_tile[wave][t & 1];
 #pragma unroll
         for (int k = 0; k < kTile / 64; ++k) {
-          uint32_t gi = (uint32_t)t * kTile + k * 64 + lane;
-          gi = gi < T ? gi : T - 1;
-          int r = 0;
-#pragma unroll
-          for (int step = 32; step > 0; step >>= 1)
-            if (rowoff[r + step] <= gi) r += step;  // largest r with rowoff[r] <= gi (empty rows share offsets)
-          if (!(flags & kAblateDma)) lds_dma16(sorted + (rowsrc[r] + (gi - rowoff[r])), buf + k * 64);
+          const uint32_t base_raw = (uint32_t)t * kTile + k * 64;
+          uint32_t idx;
+          if constexpr (decltype(fast_tag)::value) {
+            const int w = (int)(base_raw >> 6);   // < 64 on this path; windows past T hold the entry of T-1
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)w_d0, w);
+            const uint32_t ob = (uint32_t)__builtin_amdgcn_readlane((int)w_ob, w);
+            const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)w_d1, w);
+            const uint32_t gi = min(base_raw + (uint32_t)lane, T - 1);
+            idx = gi + (gi >= ob ? d1 : d0);
+          } else {
+            const uint32_t base = min(base_raw, T - 1);
+            const uint32_t gi = min(base + (uint32_t)lane, T - 1);
+            while (cur < 63 && (uint32_t)__builtin_amdgcn_readlane((int)off, cur + 1) <= base) ++cur;
+            uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)delta, cur);
+            // range starts inside the window (empty ranges share a start: the last one wins)
+            for (int j = cur + 1; j < 64; ++j) {
+              const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
+              if (oj > base + 63 || oj >= T) break;
+              const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)delta, j);
+              dl = gi >= oj ? dj : dl;
+            }
+            idx = gi + dl;
+          }
+          // uniform base + 32-bit byte offset (saddr form); clouds are < 2^28 points (checked at build)
+          const float4* gp = reinterpret_cast<const float4*>(src_bytes + (uint64_t)(idx << 4));
+          lds_dma16(gp, buf + k * 64);
         }
       };
-      issue_tile(0);
-      for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) {
-          issue_tile(t + 1);
-          // tile t landed, the kTile/64 DMAs of tile t+1 still in flight
-          if constexpr (kTile == 256) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          else if constexpr (kTile == 192) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int tn = (int)min((uint32_t)kTile, T - (uint32_t)t * kTile);
-        // The tile is read with inline-asm ds_read_b128: for an ordinary LDS load hipcc would insert
-        // s_waitcnt vmcnt(0) (it cannot tell the two buffers apart) and drain tile t+1's DMAs.
-        f32x4 p[kTile / 64];
-        const uint32_t rd = lds_addr(s_tile[wave][t & 1]) + lane * 16;
-        if constexpr (kTile == 256) {
+      auto run_tiles = [&](auto fast_tag) {
+        issue_tile(0, fast_tag);
+        for (int t = 0; t < ntiles; ++t) {
+          if (t + 1 < ntiles) {
+            issue_tile(t + 1, fast_tag);
+            // tile t landed, the 4 DMAs of tile t+1 still in flight
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_wave_barrier();
+          // The tile is read with inline-asm ds_read_b128: for an ordinary LDS load hipcc would insert
+          // s_waitcnt vmcnt(0) (it cannot tell the two buffers apart) and drain tile t+1's DMAs.
+          f32x4 p[4];
+          const uint32_t rd = lds_addr(s_tile[wave][t & 1]) + lane * 16;
           asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
                        "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
                        "s_waitcnt lgkmcnt(0)"
                        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
                        : "v"(rd)
                        : "memory");
-        } else if constexpr (kTile == 192) {
-          asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\t"
-                       "ds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2])
-                       : "v"(rd)
-                       : "memory");
-        } else {
-          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&v"(p[0]), "=&v"(p[1])
-                       : "v"(rd)
-                       : "memory");
+          // half-filled groups (cnt <= G/2, wave-uniform) skip the empty query slots
+          if (flags & kAblateCompare) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(p[k]));
+          } else if (cnt <= G / 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) compare_point<G / 4>(p[k], qx, qy, qz, best);
+          } else if (cnt <= G / 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) compare_point<G / 2>(p[k], qx, qy, qz, best);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) compare_point<G>(p[k], qx, qy, qz, best);
+          }
+          // (the reads of this buffer have returned -- waited inside the asm block -- before tile t+2's DMAs)
         }
-        // half-filled groups (cnt <= G/2, wave-uniform) skip the empty query slots
-        if (flags & kAblateCompare) {
-#pragma unroll
-          for (int k = 0; k < kTile / 64; ++k) asm volatile("" ::"v"(p[k]));
-        } else if (cnt <= G / 4) {
-#pragma unroll
-          for (int k = 0; k < kTile / 64; ++k)
-            if (k * 64 + lane < tn) compare_point<G / 4>(p[k], qx, qy, qz, best);
-        } else if (cnt <= G / 2) {
-#pragma unroll
-          for (int k = 0; k < kTile / 64; ++k)
-            if (k * 64 + lane < tn) compare_point<G / 2>(p[k], qx, qy, qz, best);
-        } else {
-#pragma unroll
-          for (int k = 0; k < kTile / 64; ++k)
-            if (k * 64 + lane < tn) compare_point<G>(p[k], qx, qy, qz, best);
-        }
-        // (the reads of this buffer have returned -- waited inside the asm block -- before tile t+2's DMAs)
-      }
+      };
+      if (fast) run_tiles(std::true_type{});
+      else run_tiles(std::false_type{});
     }
     // ---- one transposed reduction for the 8 queries; lane k fetches result k ----
     const uint64_t red = (flags & kAblateReduce) ? best[0] : wave_min8_u64(best);

@@ -20,6 +20,7 @@ struct GridParams {
   float origin[3];
   float h, inv_h;
   int dims[3];    // cells
+  int qdims[2];   // (dims[1]+1)/2, (dims[2]+1)/2: 2x2 (y,z) cell quads, see grid.h cell_index
   int bdims[3];   // blocks of kBlockCells^3 cells
   float slack;    // metres: bound on binning rounding, see nn.hip
 };

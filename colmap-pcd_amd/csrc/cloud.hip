@@ -134,7 +134,7 @@ __global__ void k_gather_sorted(const float4* __restrict__ pts4, const uint32_t*
   sorted[i] = p;
 }
 
-// one wavefront per 4x4x4-cell block: tight AABB of its points (16 rows of 4 cells, each row contiguous)
+// one wavefront per 4x4x4-cell block: tight AABB of its points (2x2 quad rows of 4 x-cells, each contiguous)
 __global__ void k_block_aabb(const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, GridParams g,
                              uint64_t nblocks, float* __restrict__ aabb) {
   const int lane = threadIdx.x & 63;
@@ -144,12 +144,12 @@ __global__ void k_block_aabb(const float4* __restrict__ sorted, const uint32_t* 
   int by = (int)((blk / g.bdims[0]) % g.bdims[1]);
   int bz = (int)(blk / ((uint64_t)g.bdims[0] * g.bdims[1]));
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int r = 0; r < kBlockCells * kBlockCells; ++r) {
-    int cy = by * kBlockCells + (r & 3), cz = bz * kBlockCells + (r >> 2);
-    if (cy >= g.dims[1] || cz >= g.dims[2]) continue;
+  for (int r = 0; r < 4; ++r) {
+    int yq = by * 2 + (r & 1), zq = bz * 2 + (r >> 1);
+    if (yq >= g.qdims[0] || zq >= g.qdims[1]) continue;
     int cx0 = bx * kBlockCells, cx1 = min(cx0 + kBlockCells, g.dims[0]);
-    uint64_t rowbase = ((uint64_t)cz * g.dims[1] + cy) * g.dims[0];
-    uint32_t s = cell_start[rowbase + cx0], e = cell_start[rowbase + cx1];
+    uint64_t rowbase = quad_row_base(g, yq, zq);
+    uint32_t s = cell_start[rowbase + 4 * cx0], e = cell_start[rowbase + 4 * cx1];
     for (uint32_t i = s + lane; i < e; i += 64) {
       float4 p = sorted[i];
       lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
@@ -204,11 +204,14 @@ static void set_dims(GridParams& g, const float lo[3], const float hi[3], float 
     ext = std::fmax(ext, (float)e);
     ext = std::fmax(ext, std::fmax(std::fabs(lo[d]), std::fabs(hi[d])));
   }
+  g.qdims[0] = (g.dims[1] + 1) / 2;
+  g.qdims[1] = (g.dims[2] + 1) / 2;
   // bound on |true coordinate - nominal cell face| caused by float binning (see nn.hip "slack")
   g.slack = ext * 9.6e-7f + 1e-30f;
 }
 
-static uint64_t num_cells(const GridParams& g) { return (uint64_t)g.dims[0] * g.dims[1] * g.dims[2]; }
+// cell table entries (quad-row order pads odd y / z extents with empty cells)
+static uint64_t num_cells(const GridParams& g) { return (uint64_t)g.dims[0] * g.qdims[0] * g.qdims[1] * 4u; }
 
 constexpr uint64_t kMaxCells = 1ull << 26;
 constexpr double kTargetOcc = 24.0;  // mean points per occupied cell

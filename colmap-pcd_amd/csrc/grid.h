@@ -16,11 +16,22 @@ __device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n) 
   int c = cell_coord_raw(p, o, inv_h, n);
   return c < 0 ? 0 : (c >= n ? n - 1 : c);
 }
+// Cell order of the sorted cloud ("quad rows"): cells are grouped in 2x2 quads in (y,z); along x the four
+// cells of a quad are adjacent:  index = ((zq * nyq + yq) * nx + x) * 4 + (z&1)*2 + (y&1).
+// Any x-range of a quad row is ONE contiguous point range, and every 2-aligned box in (y,z) -- the halo
+// regions of the bricks (B = 2, R = 2) and the 4^3 pyramid blocks -- is made of whole quad rows: 9 ranges
+// of ~110 points per brick region instead of 36 rows of ~27, 4 ranges per block instead of 16.
+__device__ __forceinline__ uint64_t quad_row_base(const GridParams& g, int yq, int zq) {
+  return ((uint64_t)zq * g.qdims[0] + yq) * (uint64_t)g.dims[0] * 4u;
+}
+__device__ __forceinline__ uint32_t cell_index(const GridParams& g, int cx, int cy, int cz) {
+  return (uint32_t)(quad_row_base(g, cy >> 1, cz >> 1) + (uint64_t)cx * 4u + (uint32_t)(((cz & 1) << 1) | (cy & 1)));
+}
 __device__ __forceinline__ uint32_t cell_of(const GridParams& g, float x, float y, float z) {
   int cx = cell_coord(x, g.origin[0], g.inv_h, g.dims[0]);
   int cy = cell_coord(y, g.origin[1], g.inv_h, g.dims[1]);
   int cz = cell_coord(z, g.origin[2], g.inv_h, g.dims[2]);
-  return (uint32_t)(((uint64_t)cz * g.dims[1] + cy) * g.dims[0] + cx);
+  return cell_index(g, cx, cy, cz);
 }
 
 // FLANN L2_Simple<float> over x,y,z: ((dx*dx) + dy*dy) + dz*dz, separate mul / add

@@ -259,7 +259,6 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
   __shared__ float s_lb[4][kMaxPyrLevels][64];
   __shared__ unsigned long long s_mask[4][kMaxPyrLevels];
   __shared__ int s_node[4][kMaxPyrLevels][3];
-  __shared__ uint32_t s_roff[4][16], s_rsrc[4][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t count = count_ptr ? *count_ptr : count_imm;
   const uint32_t nwaves = gridDim.x * 4;
@@ -312,37 +311,38 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
       ny = 4 * s_node[wave][lev][1] + ((sl >> 2) & 3);
       nz = 4 * s_node[wave][lev][2] + (sl >> 4);
       if (lev == 1) {
-        // (nx,ny,nz) is a block: its 16 rows of 4 cells along x are contiguous ranges
+        // (nx,ny,nz) is a block: 2x2 quad rows of 4 x-cells, each one contiguous point range (grid.h)
         uint32_t rs = 0, re = 0;
-        if (lane < kBlockCells * kBlockCells) {
-          const int cy = ny * kBlockCells + (lane & 3), cz = nz * kBlockCells + (lane >> 2);
-          if (cy < g.dims[1] && cz < g.dims[2]) {
+        if (lane < 4) {
+          const int yq = ny * 2 + (lane & 1), zq = nz * 2 + (lane >> 1);
+          if (yq < g.qdims[0] && zq < g.qdims[1]) {
             const int cx0 = nx * kBlockCells, cx1 = min(cx0 + kBlockCells, g.dims[0]);
-            const uint64_t rowbase = ((uint64_t)cz * g.dims[1] + cy) * g.dims[0];
-            rs = cell_start[rowbase + cx0];
-            re = cell_start[rowbase + cx1];
+            const uint64_t rowbase = quad_row_base(g, yq, zq);
+            rs = cell_start[rowbase + 4 * cx0];
+            re = cell_start[rowbase + 4 * cx1];
           }
         }
-        // The 16 row ranges are scanned as one concatenated range, 256 points per step, with the four
-        // loads of a step issued back to back (clamped indices, no branches around them): one memory
-        // round trip per 256 points instead of one per row.
+        // The 4 ranges are scanned as one concatenated range, 256 points per step, with the four loads of
+        // a step issued back to back (clamped indices, no branches around them).  Range starts and source
+        // deltas are wave-uniform (SGPRs): slot -> address is three compares, no LDS.
         uint32_t Tb;
         const uint32_t roff = wave_excl_scan_u32(re - rs, Tb);
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 16) { s_roff[wave][lane] = roff; s_rsrc[wave][lane] = rs; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)roff, 1);
+        const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)roff, 2);
+        const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)roff, 3);
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)rs, 0);
+        const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)rs, 1) - o1;
+        const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)rs, 2) - o2;
+        const uint32_t d3 = (uint32_t)__builtin_amdgcn_readlane((int)rs, 3) - o3;
         for (uint32_t base = 0; base < Tb; base += 256) {
           float4 p[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             uint32_t gi = base + k * 64 + lane;
             gi = gi < Tb ? gi : Tb - 1;
-            int r = 0;
-#pragma unroll
-            for (int step = 8; step > 0; step >>= 1)
-              if (s_roff[wave][r + step] <= gi) r += step;
-            p[k] = sorted[s_rsrc[wave][r] + (gi - s_roff[wave][r])];
+            // empty ranges share their offset with the next one: test from the last range down
+            const uint32_t dl = gi >= o3 ? d3 : gi >= o2 ? d2 : gi >= o1 ? d1 : d0;
+            p[k] = sorted[gi + dl];
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
