@@ -168,3 +168,55 @@ def test_midsize_vs_kdtree_oracle_and_gpu_bruteforce(gpu, oracle):
     assert np.array_equal(d.view(np.uint32), gd.view(np.uint32))
     st = c.last_stats()
     c.close()
+
+
+def test_full_size_properties(gpu):
+    """BASELINE.json's size (10 M-point cloud, 1 M queries): too large for the CPU oracle in a test, so the
+    result is checked through properties that do not depend on the size:
+      * the returned squared distance is bit-for-bit the FLANN float distance to the returned row;
+      * a 4096-query sample equals the GPU brute force over all 10 M rows (itself oracle-checked above);
+      * querying cloud rows themselves gives distance 0 and an index whose row has identical coordinates,
+        never a higher index than the queried row (ties go to the lowest index);
+      * splitting the cloud in two interleaved shards and taking the per-query minimum of the packed keys
+        reproduces the single-cloud keys (the cloud-sharded multi-GPU path, dist.py)."""
+    import torch
+    N, Q = 10_000_000, 1_000_000
+    xyz, nrm = synth.cloud_planes(N)
+    q = synth.queries(xyz, Q)
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    dq = torch.from_numpy(q).cuda()
+    keys = torch.empty(Q, dtype=torch.int64, device="cuda")
+    c.nn_device(dq, Q, keys)
+    torch.cuda.synchronize()
+    k = keys.cpu().numpy().view(np.uint64)
+    assert (k != np.uint64(gpu.KEY_NONE)).all()
+    gi = (k & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    gd = (k >> np.uint64(32)).astype(np.uint32)
+    qf = q.astype(np.float32)
+    p = xyz[gi]
+    dx, dy, dz = qf[:, 0] - p[:, 0], qf[:, 1] - p[:, 1], qf[:, 2] - p[:, 2]
+    d = (dx * dx + dy * dy) + dz * dz
+    assert np.array_equal(d.view(np.uint32), gd)
+    # sample vs brute force over the whole cloud
+    kb = torch.empty(4096, dtype=torch.int64, device="cuda")
+    sel = torch.from_numpy(np.random.default_rng(1).choice(Q, 4096, replace=False)).cuda()
+    c.nn_device(dq[sel].contiguous(), 4096, kb, gpu.NN_BRUTEFORCE)
+    torch.cuda.synchronize()
+    assert torch.equal(kb, keys[sel])
+    # cloud rows as queries
+    rows = np.random.default_rng(2).choice(N, 200_000, replace=False)
+    ri, rd, rf = c.nn(xyz[rows].astype(np.float64))
+    assert rf.all() and not rd.any()
+    assert np.array_equal(xyz[ri], xyz[rows]) and (ri <= rows).all()
+    c.close()
+    # two interleaved shards, combined by the minimum of the keys
+    Qs = 200_000
+    ks = []
+    for r in range(2):
+        cs = gpu.Cloud(xyz[r::2], nrm[r::2], raw_lidar_frame=False, index_base=r, index_stride=2)
+        kk = torch.empty(Qs, dtype=torch.int64, device="cuda")
+        cs.nn_device(dq[:Qs].contiguous(), Qs, kk)
+        torch.cuda.synchronize()
+        ks.append(kk.clone())
+        cs.close()
+    assert torch.equal(torch.minimum(ks[0], ks[1]), keys[:Qs])
