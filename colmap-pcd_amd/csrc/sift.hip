@@ -314,4 +314,78 @@ pcd_status pcd_sift_match(int device, const uint8_t* desc1, int n1, const uint8_
   return PCD_OK;
 }
 
+// ---- matcher handle: two descriptor slots resident on the device (SiftMatchGPU's usage pattern) ----
+}  // extern "C"
+
+struct pcd_sift_matcher {
+  int device = 0;
+  int max_sift = 4096;
+  int n[2] = {0, 0};
+  pcd::DevBuf<uint8_t> d[2];
+  pcd::DevBuf<int32_t> m12, m21, count;
+  pcd::DevBuf<uint32_t> matches;
+};
+
+extern "C" {
+
+pcd_status pcd_sift_matcher_create(int device, int max_sift, pcd_sift_matcher** out) {
+  PCD_REQUIRE(out && max_sift > 0, "null pointer / max_sift");
+  PCD_REQUIRE(device >= 0 && device < 64, "device ordinal");
+  PCD_TRY(require_device(device));
+  pcd_sift_matcher* m = new pcd_sift_matcher();
+  m->device = device;
+  m->max_sift = max_sift;
+  *out = m;
+  return PCD_OK;
+}
+
+void pcd_sift_matcher_destroy(pcd_sift_matcher* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  delete m;
+}
+
+pcd_status pcd_sift_matcher_set_max_sift(pcd_sift_matcher* m, int max_sift) {
+  PCD_REQUIRE(m && max_sift > 0, "null pointer / max_sift");
+  m->max_sift = max_sift;
+  return PCD_OK;
+}
+
+// SiftMatchGPU::SetDescriptors(index, num, const unsigned char*): num is clipped to max_sift
+pcd_status pcd_sift_matcher_set_descriptors(pcd_sift_matcher* m, int index, int num, const uint8_t* desc) {
+  PCD_REQUIRE(m && (index == 0 || index == 1) && num >= 0, "index must be 0 or 1");
+  PCD_REQUIRE(num == 0 || desc, "null descriptors");
+  PCD_HIP_TRY(hipSetDevice(m->device));
+  if (num > m->max_sift) num = m->max_sift;
+  m->n[index] = num;
+  if (num) {
+    PCD_TRY(m->d[index].reserve((size_t)num * 128));
+    PCD_HIP_TRY(hipMemcpy(m->d[index].p, desc, (size_t)num * 128, hipMemcpyHostToDevice));
+  }
+  return PCD_OK;
+}
+
+// SiftMatchGPU::GetSiftMatch: number of matches written (at most max_match, in ascending index of set 0)
+pcd_status pcd_sift_matcher_match(pcd_sift_matcher* m, int max_match, uint32_t* matches, float distmax, float ratiomax,
+                                  int mutual_best_match, int32_t* num_matches) {
+  PCD_REQUIRE(m && num_matches && max_match >= 0, "null pointer");
+  *num_matches = 0;
+  const int n1 = m->n[0], n2 = m->n[1];
+  if (n1 == 0 || n2 == 0 || max_match == 0) return PCD_OK;
+  PCD_REQUIRE(matches, "null match buffer");
+  PCD_HIP_TRY(hipSetDevice(m->device));
+  PCD_TRY(m->m12.reserve(n1)); PCD_TRY(m->m21.reserve(n2)); PCD_TRY(m->matches.reserve(2 * (size_t)n1));
+  PCD_TRY(m->count.reserve(1));
+  hipStream_t s = nullptr;
+  PCD_TRY(pcd_sift_match_device(m->device, m->d[0].p, n1, m->d[1].p, n2, ratiomax, distmax, mutual_best_match,
+                                m->m12.p, m->m21.p, m->matches.p, m->count.p, s));
+  int cnt = 0;
+  PCD_HIP_TRY(hipMemcpyAsync(&cnt, m->count.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  PCD_HIP_TRY(hipStreamSynchronize(s));
+  if (cnt > max_match) cnt = max_match;
+  if (cnt) PCD_HIP_TRY(hipMemcpy(matches, m->matches.p, 2 * (size_t)cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  *num_matches = cnt;
+  return PCD_OK;
+}
+
 }  // extern "C"

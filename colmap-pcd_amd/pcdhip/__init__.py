@@ -96,6 +96,8 @@ ABI_SYMBOLS = [
     "pcd_filter_lidar_outlier_device", "pcd_ba_observation_errors", "pcd_ba_observation_errors_device",
     "pcd_proj_default_options", "pcd_proj_create", "pcd_proj_destroy", "pcd_proj_num_submaps",
     "pcd_proj_last_pairs", "pcd_proj_scale_coeffs", "pcd_proj_set_new_images",
+    "pcd_sift_matcher_create", "pcd_sift_matcher_destroy", "pcd_sift_matcher_set_max_sift",
+    "pcd_sift_matcher_set_descriptors", "pcd_sift_matcher_match",
 ]
 
 

@@ -11,6 +11,8 @@
 #include <random>
 
 #include "ba_problem.h"
+#include "pose_reader.h"
+#include "sift_match_hip.h"
 #include "lidar_hip.h"
 
 using namespace colmap_hip;
@@ -203,6 +205,34 @@ static void TestMatchVariablePoint() {
   CHECK(MatchVariablePoint2LidarPoint(searched, 42, X, only5, &lp) && lp.xyz[0] == 1.0 && lp.angle == 1.0);
 }
 
+// LoadPose (controllers/incremental_mapper.cc:920-996) on hand-computed poses
+static void TestPoseReader() {
+  const std::string path = "/tmp/pcdhip_pose_test.ply";
+  {
+    std::ofstream f(path);
+    f << "ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nend_header\n";
+    f << "1 2 3 0 0 0\n";                       // image 1: pure translation
+    f << "0 0 0 nan 0 0\n";                     // image 2: skipped, but the id advances
+    f << "0 0 0 0 0 1.5707963267948966\n";      // image 3: yaw +90 deg (turn left)
+    f << "5 0 0 0 0 3.141592653589793\n";       // image 4: trace <= 0 branch of the quaternion extraction
+  }
+  std::map<uint32_t, std::array<double, 7>> poses;
+  CHECK(LoadPosePly(path, &poses));
+  CHECK_EQ(poses.size(), 3u);
+  CHECK(poses.count(1) && !poses.count(2) && poses.count(3) && poses.count(4));
+  // image 1: R = I, t_wc = (-2, -3, 1) -> t_cw = (2, 3, -1), q = (1, 0, 0, 0)
+  CHECK(poses[1][0] == 2 && poses[1][1] == 3 && poses[1][2] == -1 && poses[1][3] == 1 && poses[1][4] == 0);
+  // image 3: R_wc = Ry(-90 deg): the camera's optical axis (0,0,1) looks along world (-1,0,0) = LiDAR +y (left)
+  const double h = std::sqrt(0.5);
+  CHECK(std::fabs(poses[3][3] - h) < 1e-15 && std::fabs(poses[3][5] - h) < 1e-15);      // q_cw = (c, 0, +s, 0)
+  CHECK(std::fabs(poses[3][4]) < 1e-15 && std::fabs(poses[3][6]) < 1e-15);
+  // image 4: half turn about the vertical axis; t_wc = (0, 0, 5), R_cw t = (0,0,-5) -> t_cw = (0, 0, 5)
+  CHECK(std::fabs(std::fabs(poses[4][5]) - 1.0) < 1e-15 && std::fabs(poses[4][3]) < 1e-15);
+  CHECK(std::fabs(poses[4][2] - 5.0) < 1e-12 && std::fabs(poses[4][0]) < 1e-12);
+  std::remove(path.c_str());
+  CHECK(!LoadPosePly("/tmp/pcdhip_no_such_pose.ply", &poses));
+}
+
 static void TestPlyReader() {
   std::vector<float> xyz, nrm;
   std::mt19937 rng(3);
@@ -223,6 +253,37 @@ static void TestPlyReader() {
   }
   std::vector<float> a, b;
   CHECK(!ReadPlyXYZNormal("/tmp/pcdhip_does_not_exist.ply", &a, &b));   // load failure -> false (ply.cc:14-17)
+}
+
+// SiftMatchGPU-shaped adapter on the hand-made descriptors of feature/sift_test.cc (two unit descriptors each:
+// expected 2 matches (0,0),(1,1) [ref]; with the second set's rows swapped the matches follow)
+static int TestGpuSiftMatcher() {
+  std::vector<unsigned char> d1(2 * 128, 0), d2(2 * 128, 0);
+  for (int k = 0; k < 4; ++k) {            // two orthogonal descriptors of norm 510 (~ the 512 of real SIFT rows):
+    d1[k] = d2[k] = 255;                   // dot 260100 -> acos(0.992) = 0.13 < 0.7, second best 0 -> ratio passes
+    d1[128 + 4 + k] = d2[128 + 4 + k] = 255;
+  }
+  SiftMatchHIP m(4096);
+  CHECK(m.VerifyContextGL());
+  m.SetDescriptors(0, 2, d1.data());
+  m.SetDescriptors(1, 2, d2.data());
+  uint32_t buf[8][2];
+  CHECK_EQ(m.GetSiftMatch(8, buf), 2);
+  CHECK(buf[0][0] == 0 && buf[0][1] == 0 && buf[1][0] == 1 && buf[1][1] == 1);
+  std::swap_ranges(d2.begin(), d2.begin() + 128, d2.begin() + 128);
+  m.SetDescriptors(1, 2, d2.data());       // slot 0 stays resident
+  CHECK_EQ(m.GetSiftMatch(8, buf), 2);
+  CHECK(buf[0][0] == 0 && buf[0][1] == 1 && buf[1][0] == 1 && buf[1][1] == 0);
+  CHECK_EQ(m.GetSiftMatch(1, buf), 1);     // max_match clips
+  m.SetDescriptors(1, 0, nullptr);
+  CHECK_EQ(m.GetSiftMatch(8, buf), 0);     // empty set: no matches
+  m.SetMaxSift(1);
+  m.SetDescriptors(0, 2, d1.data());       // clipped to one descriptor each
+  m.SetDescriptors(1, 2, d2.data());       // (rows swapped above: first rows are orthogonal)
+  CHECK_EQ(m.GetSiftMatch(8, buf), 0);
+  m.SetDescriptors(1, 2, d1.data());
+  CHECK_EQ(m.GetSiftMatch(8, buf), 1);
+  return 0;
 }
 
 // PcdProj mirror: wall z = 10 m in front of a camera at the origin (pinhole 3039 px, 4032 x 3024)
@@ -337,7 +398,7 @@ static int TestGpu() {
   for (double r : res) s += r * r;
   CHECK(std::fabs(cost - 0.5 * s) <= 1e-9 * cost);
   CHECK(cost > 0 && cost < 300 * 8.0 + 1e4);   // +-2 px noise on 300 observations + one lidar term
-  return TestGpuProjection();
+  return TestGpuProjection() + TestGpuSiftMatcher();
 }
 
 int main(int argc, char** argv) {
@@ -347,6 +408,7 @@ int main(int argc, char** argv) {
   TestForceToOptimizePoint();
   TestLidarBlocks();
   TestPlyReader();
+  TestPoseReader();
   TestMatchVariablePoint();
   if (argc > 1 && std::strcmp(argv[1], "--gpu") == 0) g_fail += TestGpu();
   std::printf(g_fail ? "%d FAILED\n" : "ALL OK\n", g_fail);

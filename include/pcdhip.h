@@ -365,6 +365,19 @@ pcd_status pcd_sift_match_device(int device, const uint8_t* d_desc1, int n1, con
                                  float max_ratio, float max_distance, int cross_check, int32_t* d_m12,
                                  int32_t* d_m21, uint32_t* d_matches, int32_t* d_num_matches, void* stream);
 
+/* Matcher object with the shape of lib/SiftGPU's SiftMatchGPU (lib/SiftGPU/SiftGPU.h:268-352) as the reference
+ * drives it in feature/sift.cc:1227-1266 MatchSiftFeaturesGPU: two descriptor slots stay on the device, so
+ * matching image i against many j uploads i once.  set_descriptors clips num to max_sift like
+ * SiftMatchGPU::SetDescriptors; match = GetSiftMatch(max_match, match_buffer, distmax, ratiomax,
+ * mutual_best_match) and returns the exact brute-force result (see above). */
+typedef struct pcd_sift_matcher pcd_sift_matcher;
+pcd_status pcd_sift_matcher_create(int device, int max_sift, pcd_sift_matcher** out);
+void pcd_sift_matcher_destroy(pcd_sift_matcher* m);
+pcd_status pcd_sift_matcher_set_max_sift(pcd_sift_matcher* m, int max_sift);
+pcd_status pcd_sift_matcher_set_descriptors(pcd_sift_matcher* m, int index /*0|1*/, int num, const uint8_t* desc);
+pcd_status pcd_sift_matcher_match(pcd_sift_matcher* m, int max_match, uint32_t* matches /*[max_match][2]*/,
+                                  float distmax, float ratiomax, int mutual_best_match, int32_t* num_matches);
+
 /* ------------------------------------------------------------------------
  * Profiling hooks used by bench.py (HIP events on the launch stream)
  * --------------------------------------------------------------------- */
