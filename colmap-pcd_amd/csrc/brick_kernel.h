@@ -265,8 +265,8 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
             }
             idx = gi + dl;
           }
-          // uniform base + 32-bit byte offset (saddr form); clouds are < 2^28 points (checked at build)
-          const float4* gp = reinterpret_cast<const float4*>(src_bytes + (uint64_t)(idx << 4));
+          // uniform base + byte offset (64-bit: a cloud may exceed 2^28 points = 4 GiB of records)
+          const float4* gp = reinterpret_cast<const float4*>(src_bytes + ((uint64_t)idx << 4));
           lds_dma16(gp, buf + k * 64);
         }
       };
