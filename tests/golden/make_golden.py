@@ -44,6 +44,25 @@ def nn_small():
     np.savez_compressed(os.path.join(HERE, "assoc_small.npz"), out6=out6, ok=ok, max_range=mr, **res)
 
 
+def proj_small():
+    """Depth-projection association (lidar/pcd_projection.cc): 30 k points, 3 images, 400 features each."""
+    box = np.array([30.0, 10.0, 30.0])
+    xyz, nrm = synth.cloud_uniform(30_000, seed=12, box=box)
+    images, feat = synth.proj_scene(3, 400, seed=21, scene_box=box)
+    oo = po.proj_options()
+    coeffs = po.proj_scale_coeffs(oo, images[0]["params"][0], images[0]["params"][1])
+    found, index, dist, l6, cam, pairs = po.proj_images(xyz, nrm, oo, coeffs, images, feat)
+    assert 0 < found.sum() < found.size
+    np.savez_compressed(os.path.join(HERE, "proj_small.npz"), xyz=xyz, nrm=nrm, feat=feat, coeffs=coeffs,
+                        qvec=np.array([im["qvec"] for im in images]), tvec=np.array([im["tvec"] for im in images]),
+                        params=np.array([im["params"] for im in images]),
+                        size=np.array([[im["width"], im["height"]] for im in images], np.int64),
+                        feat_range=np.array([[im["feat_begin"], im["feat_end"]] for im in images], np.int64),
+                        min_lidar_proj_dist=np.float64(oo.min_lidar_proj_dist),
+                        found=found, index=index, dist_bits=dist.view(np.uint32), cam_xyz=cam, pairs=np.int64(pairs))
+
+
 if __name__ == "__main__":
     nn_small()
+    proj_small()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

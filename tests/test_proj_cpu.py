@@ -75,3 +75,21 @@ def test_depth_gates(oracle):
     assert found[0] == 1
     (found, *_), _ = _run(oracle, [[-1.43, 0, 2.2]], [[-5.1, 1512]], submap=0.1)     # pixel -1: outside
     assert found[0] == 0
+
+
+def _golden():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "proj_small.npz"))
+    images = [dict(qvec=g["qvec"][i].tolist(), tvec=g["tvec"][i].tolist(), params=g["params"][i].tolist(),
+                   width=int(g["size"][i, 0]), height=int(g["size"][i, 1]), feat_begin=int(g["feat_range"][i, 0]),
+                   feat_end=int(g["feat_range"][i, 1])) for i in range(g["qvec"].shape[0])]
+    return g, images
+
+
+def test_oracle_reproduces_committed_fixture(oracle):
+    g, images = _golden()
+    oo = oracle.proj_options(min_lidar_proj_dist=float(g["min_lidar_proj_dist"]))
+    found, index, dist, l6, cam, pairs = oracle.proj_images(g["xyz"], g["nrm"], oo, g["coeffs"], images, g["feat"])
+    assert np.array_equal(found, g["found"]) and np.array_equal(index, g["index"])
+    assert np.array_equal(dist.view(np.uint32), g["dist_bits"]) and pairs == int(g["pairs"])
+    assert np.array_equal(cam, g["cam_xyz"])

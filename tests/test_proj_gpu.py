@@ -102,3 +102,18 @@ def test_proj_coeffs_latch_on_first_camera(gpu, oracle):
     _compare(got2, exp2)
     pj.close()
     cloud.close()
+
+
+def test_proj_golden_fixture(gpu):
+    """committed vectors (tests/golden/proj_small.npz, generator make_golden.py): no oracle needed at run time"""
+    from tests.test_proj_cpu import _golden
+    g, images = _golden()
+    cloud = gpu.Cloud(g["xyz"], g["nrm"], raw_lidar_frame=False)
+    pj = gpu.Projector(cloud, min_lidar_proj_dist=float(g["min_lidar_proj_dist"]))
+    found, index, dist, l6, cam = pj.set_new_images(images, g["feat"])
+    assert np.array_equal(found, g["found"]) and np.array_equal(index, g["index"])
+    assert np.array_equal(dist.view(np.uint32), g["dist_bits"])
+    np.testing.assert_allclose(cam, g["cam_xyz"], rtol=1e-12, atol=0)
+    assert pj.last_pairs == int(g["pairs"])
+    pj.close()
+    cloud.close()

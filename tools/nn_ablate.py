@@ -15,8 +15,8 @@ c = pcdhip.Cloud(xyz, nrm, raw_lidar_frame=False)
 dq = torch.from_numpy(q).cuda()
 keys = torch.empty(Q, dtype=torch.int64, device="cuda")
 F = 0x800  # never hand anything to the fallback (keeps the brick kernel's control flow comparable)
-for name, fl in [("full", 0), ("full, no fallback list", F), ("no-compare", F | 0x100), ("no-dma", F | 0x200),
-                 ("no-reduce", F | 0x400), ("no-compare+no-dma", F | 0x300), ("no-compare+no-dma+no-reduce", F | 0x700), ("no tile loop at all, no reduce", F | 0x1400), ("no tile loop", F | 0x1000),
+for name, fl in [("full", 0), ("full, no fallback list", F), ("no-compare", F | 0x100), ("no-reduce", F | 0x400),
+                 ("no-compare+no-reduce", F | 0x500), ("no tile loop, no reduce", F | 0x1400), ("no tile loop", F | 0x1000),
                  ("full", 0)]:
     pcdhip.set_nn_tuning(0, -1, fl)
     for _ in range(3):
