@@ -35,9 +35,13 @@ constexpr int kSiftTile = 128;
 constexpr int kSiftPitch = 144;   // bytes per staged descriptor row (128 + 16 pad)
 constexpr int kSiftConst = 128 * 128 * 128;
 
-__global__ void k_sift_rowsum(const uint8_t* __restrict__ d, int n, int* __restrict__ sum) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__global__ void k_sift_rowsum(const uint8_t* __restrict__ da, int na, int* __restrict__ suma,
+                              const uint8_t* __restrict__ db, int nb, int* __restrict__ sumb) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= na + nb) return;
+  const uint8_t* d = i < na ? da : db;
+  int* sum = i < na ? suma : sumb;
+  if (i >= na) i -= na;
   const uint4* p = reinterpret_cast<const uint4*>(d + (size_t)i * 128);
   unsigned s = 0;
 #pragma unroll
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void k_sift_scores(const uint8_t* __restrict__
   __shared__ __attribute__((aligned(16))) uint8_t sA[kSiftTile * kSiftPitch];
   __shared__ __attribute__((aligned(16))) uint8_t sB[kSiftTile * kSiftPitch];
   __shared__ int sSumA[kSiftTile], sSumB[kSiftTile];
-  __shared__ int4 sMerge[2][2][64];   // [direction][wave half][column in the 64-wide half]... see below
+  __shared__ int2 sMerge[2][2][64];   // [direction][64-column half][column]: packed (best, second) of the upper row half
   const int bx = blockIdx.x, by = blockIdx.y;           // bx: tile of set 2 (columns), by: tile of set 1 (rows)
   const int row0 = by * kSiftTile, col0 = bx * kSiftTile;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,13 +102,17 @@ __global__ __launch_bounds__(256) void k_sift_scores(const uint8_t* __restrict__
   __syncthreads();
 
   // ---- 64 x 64 per wavefront, both orientations from the same fragments ----
+  // The accumulators start at 128 * rowsum(row) (exact int32), so the scan below needs no per-element add.
   v16i acc1[2][2], acc2[2][2];   // acc1[mt][nt]: rows = set-1, cols = set-2;  acc2[nt][mt]: rows = set-2, cols = set-1
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int k = 0; k < 16; ++k) {
+      const int rr = a * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+      const int ra = 128 * sSumA[wr * 64 + rr], rb = 128 * sSumB[wc * 64 + rr];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { acc1[a][b][k] = 0; acc2[a][b][k] = 0; }
+      for (int c = 0; c < 2; ++c) { acc1[a][c][k] = ra; acc2[a][c][k] = rb; }
+    }
   const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
@@ -125,8 +133,12 @@ __global__ __launch_bounds__(256) void k_sift_scores(const uint8_t* __restrict__
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
   // Direction 2 -> 1 (for every set-2 descriptor j the best set-1 rows): acc1, lane owns column j.
-  // The column constant 128*sum2[j] - 128^3 does not change the order inside a column, so the scan runs on
-  // acc + 128*sum1[i] with the thresholds shifted by the constant, which is added back at the end.
+  // The column constant 128*sum2[j] - 128^3 does not change the order inside a column, so the scan runs on the
+  // accumulators as they are and the constant is added back at the end.
+  // Packed scan: value = score << 8 | (255 - row in the 128-row tile).  Scores are < 2^23 in magnitude and the
+  // code is unique per row and larger for lower rows, so a signed max picks the higher score and, at equal
+  // scores, the lower row -- the reference's ascending strict-> scan (sift.cc:72-84) -- and the running second
+  // best is the median of (best, second, value): 3 VALU per score (shift-or, max, med3) and no index tracking.
 #pragma unroll
   for (int dir = 0; dir < 2; ++dir) {
 #pragma unroll
@@ -134,56 +146,77 @@ __global__ __launch_bounds__(256) void k_sift_scores(const uint8_t* __restrict__
       // dir 0: columns = set 2 (wc, nt = ct), rows = set 1 (wr, mt);  dir 1: columns = set 1 (wr, mt = ct), rows = set 2 (wc, nt)
       const int ccol = (dir == 0 ? wc : wr) * 64 + ct * 32 + lr;            // column inside the 128 tile
       const int cconst = 128 * (dir == 0 ? sSumB[ccol] : sSumA[ccol]) - kSiftConst;
-      int best = -cconst, second = -cconst, arg = -1;                        // true values start at 0 (sift.cc:66-68)
+      const int other = dir == 0 ? wr : wc;          // which of the two 64-row halves this wavefront holds
+      const int colhalf = dir == 0 ? wc : wr;        // which 64-column half
+      const int init = (int)((unsigned)(-cconst) << 8);   // true score 0, code 0 = "no row" (sift.cc:66-68)
+      const unsigned code_base = 255u - (unsigned)(other * 64 + 4 * lh);
+      int best = init, second = init;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const v16i& acc = dir == 0 ? acc1[rt][ct] : acc2[rt][ct];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-          const int rrow = (dir == 0 ? wr : wc) * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-          const int v = acc[reg] + 128 * (dir == 0 ? sSumA[rrow] : sSumB[rrow]);
-          top2_update(v, (dir == 0 ? row0 : col0) + rrow, best, second, arg);
+          const unsigned code = code_base - (unsigned)(rt * 32 + (reg & 3) + 8 * (reg >> 2));
+          const int v = (int)(((unsigned)acc[reg] << 8) | code);
+          int med;
+          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(med) : "v"(best), "v"(second), "v"(v));
+          second = med;
+          best = max(best, v);
         }
       }
       // the two lane halves hold interleaved rows of the same column
       {
-        const int b2 = __shfl_xor(best, 32), s2 = __shfl_xor(second, 32), a2 = __shfl_xor(arg, 32);
-        top2_merge(b2, s2, a2, best, second, arg);
+        const int b2 = __shfl_xor(best, 32), s2 = __shfl_xor(second, 32);
+        second = max(max(second, s2), min(best, b2));
+        best = max(best, b2);
       }
       // merge the two wavefronts that share these columns (dir 0: wr = 0,1; dir 1: wc = 0,1) through LDS
-      const int other = dir == 0 ? wr : wc;          // which of the two row halves this wavefront holds
-      const int colhalf = dir == 0 ? wc : wr;        // which 64-column half
-      if (other == 1 && lh == 0) sMerge[dir][colhalf][ct * 32 + lr] = make_int4(best, second, arg, 0);
+      if (other == 1 && lh == 0) sMerge[dir][colhalf][ct * 32 + lr] = make_int2(best, second);
       __syncthreads();
       if (other == 0 && lh == 0) {
-        const int4 o = sMerge[dir][colhalf][ct * 32 + lr];
-        top2_merge(o.x, o.y, o.z, best, second, arg);   // rows of `other == 1` are higher: ties keep ours
-        best += cconst;
-        second += cconst;
+        const int2 o = sMerge[dir][colhalf][ct * 32 + lr];
+        second = max(max(second, o.y), min(best, o.x));
+        best = max(best, o.x);
+        const int bs = (best >> 8) + cconst, ss = (second >> 8) + cconst;      // true scores (>= 0)
+        const int arg = bs > 0 ? (dir == 0 ? row0 : col0) + 255 - (best & 255) : -1;   // strict >: a zero score never matches
         const int gcol = (dir == 0 ? col0 : row0) + ccol;
-        if (dir == 0) { if (gcol < n2) part21[(size_t)gcol * nby + by] = make_int4(best, second, arg, 0); }
-        else { if (gcol < n1) part12[(size_t)gcol * nbx + bx] = make_int4(best, second, arg, 0); }
+        // partials are [tile][descriptor]: coalesced here and in the merge kernel
+        if (dir == 0) { if (gcol < n2) part21[(size_t)by * n2 + gcol] = make_int4(bs, ss, arg, 0); }
+        else { if (gcol < n1) part12[(size_t)bx * n1 + gcol] = make_int4(bs, ss, arg, 0); }
       }
       __syncthreads();
     }
   }
 }
 
-// sift.cc:72-104: merge the per-tile triples in ascending tile order, then the distance / ratio tests
-__global__ void k_sift_finalize(const int4* __restrict__ part, int n, int nb, float max_ratio, float max_distance,
-                                int* __restrict__ match) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// sift.cc:72-104: merge the per-tile triples in ascending tile order, then the distance / ratio tests.
+// One launch for both directions: threads [0, n1) finish set 1 -> 2, threads [n1, n1 + n2) set 2 -> 1.
+__global__ __launch_bounds__(256) void k_sift_finalize(const int4* __restrict__ part12, int n1, int nbx,
+                                                       const int4* __restrict__ part21, int n2, int nby,
+                                                       float max_ratio, float max_distance, int* __restrict__ m12,
+                                                       int* __restrict__ m21) {
+  // 16 lanes per descriptor: lane p merges tiles p, p + 16, ... in ascending order, then a 4-step butterfly.
+  // On equal best scores the lower index wins, which is the earlier tile (indices ascend with the tile) --
+  // the same winner as the reference's single ascending scan.
+  const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, p = threadIdx.x & 15;
+  if (g >= n1 + n2) return;
+  const bool first = g < n1;
+  const int4* __restrict__ part = first ? part12 : part21;
+  const int n = first ? n1 : n2, nb = first ? nbx : nby;
+  const int i = first ? g : g - n1;
   int best = 0, second = 0, arg = -1;
-  for (int b = 0; b < nb; ++b) {
-    const int4 p = part[(size_t)i * nb + b];
-    // ascending order: an equal best from a later tile does not replace the earlier one (strict >)
-    const int nsecond = max(max(second, p.y), min(best, p.x));
-    if (p.x > best) { arg = p.z; best = p.x; }
-    second = nsecond;
+  for (int b = p; b < nb; b += 16) {
+    const int4 v = part[(size_t)b * n + i];
+    top2_merge(v.x, v.y, v.z, best, second, arg);
   }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    const int b2 = __shfl_xor(best, o), s2 = __shfl_xor(second, o), a2 = __shfl_xor(arg, o);
+    top2_merge(b2, s2, a2, best, second, arg);
+  }
+  if (p != 0) return;
   int m = -1;
-  if (arg != -1) {
+  if (arg != -1 && best > 0) {
     const float kDistNorm = 1.0f / (512.0f * 512.0f);
     const float bn = acosf(fminf(kDistNorm * (float)best, 1.0f));
     if (!(bn > max_distance)) {
@@ -191,7 +224,53 @@ __global__ void k_sift_finalize(const int4* __restrict__ part, int n, int nb, fl
       if (!(bn >= max_ratio * sn)) m = arg;
     }
   }
-  match[i] = m;
+  (first ? m12 : m21)[i] = m;
+}
+
+// sift.cc:118-143 for n1 <= 1024 * kCompactPer: cross check, ordered compaction and count in ONE workgroup
+// (a launch costs more than the work: 8192 flags).  Larger sets take the three-kernel path below.
+constexpr int kCompactPer = 16;
+__global__ __launch_bounds__(1024) void k_sift_keep_compact(const int* __restrict__ m12, const int* __restrict__ m21,
+                                                            int n1, int cross_check, uint32_t* __restrict__ matches,
+                                                            int* __restrict__ count) {
+  __shared__ uint32_t s_wave[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n1 + 1023) / 1024;            // <= kCompactPer consecutive rows per thread
+  const int i0 = tid * per;
+  uint32_t flags = 0, cnt = 0;
+  for (int k = 0; k < per; ++k) {
+    const int i = i0 + k;
+    bool keep = false;
+    if (i < n1) {
+      const int j = m12[i];
+      keep = j != -1;
+      if (keep && cross_check) keep = (m21[j] != -1) && (m21[j] == i);
+    }
+    flags |= (keep ? 1u : 0u) << k;
+    cnt += keep ? 1u : 0u;
+  }
+  // exclusive scan of cnt over the 1024 threads: DPP-free shuffle scan inside the wave, LDS across waves
+  uint32_t inc = cnt;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    const uint32_t c = s_wave[w];
+    if (w < wave) base += c;
+    total += c;
+  }
+  uint32_t pos = base + inc - cnt;
+  for (int k = 0; k < per; ++k)
+    if ((flags >> k) & 1u) {
+      matches[2 * pos] = (uint32_t)(i0 + k);
+      matches[2 * pos + 1] = (uint32_t)m12[i0 + k];
+      ++pos;
+    }
+  if (tid == 0) *count = (int)total;
 }
 
 // sift.cc:118-143: keep flags, in set-1 order
@@ -232,8 +311,8 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
   PCD_TRY(sc.keep.reserve(n1)); PCD_TRY(sc.pos.reserve(n1));
   {
     ScopedKernelTimer t("sift_rowsum", s);
-    hipLaunchKernelGGL(k_sift_rowsum, dim3(div_up(n1, 256)), dim3(256), 0, s, d_d1, n1, sc.sum1.p);
-    hipLaunchKernelGGL(k_sift_rowsum, dim3(div_up(n2, 256)), dim3(256), 0, s, d_d2, n2, sc.sum2.p);
+    hipLaunchKernelGGL(k_sift_rowsum, dim3(div_up((uint64_t)n1 + n2, 256)), dim3(256), 0, s, d_d1, n1, sc.sum1.p, d_d2, n2,
+                       sc.sum2.p);
   }
   {
     ScopedKernelTimer t("sift_scores", s);
@@ -242,17 +321,23 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
   }
   {
     ScopedKernelTimer t("sift_finalize", s);
-    hipLaunchKernelGGL(k_sift_finalize, dim3(div_up(n1, 256)), dim3(256), 0, s, sc.part12.p, n1, nbx, max_ratio,
-                       max_distance, d_m12);
-    hipLaunchKernelGGL(k_sift_finalize, dim3(div_up(n2, 256)), dim3(256), 0, s, sc.part21.p, n2, nby, max_ratio,
-                       max_distance, d_m21);
-    hipLaunchKernelGGL(k_sift_keep, dim3(div_up(n1, 256)), dim3(256), 0, s, d_m12, d_m21, n1, cross_check, sc.keep.p);
-    size_t tb = 0;
-    PCD_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, sc.keep.p, sc.pos.p, 0u, (size_t)n1, rocprim::plus<uint32_t>(), s));
-    PCD_TRY(sc.tmp.reserve(tb));
-    PCD_HIP_TRY(rocprim::exclusive_scan(sc.tmp.p, tb, sc.keep.p, sc.pos.p, 0u, (size_t)n1, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL(k_sift_compact, dim3(div_up(n1, 256)), dim3(256), 0, s, d_m12, sc.keep.p, sc.pos.p, n1,
-                       d_matches, d_count);
+    hipLaunchKernelGGL(k_sift_finalize, dim3(div_up(((uint64_t)n1 + n2) * 16, 256)), dim3(256), 0, s, sc.part12.p, n1, nbx,
+                       sc.part21.p, n2, nby, max_ratio, max_distance, d_m12, d_m21);
+  }
+  {
+    ScopedKernelTimer t("sift_compact", s);
+    if (n1 <= 1024 * kCompactPer) {
+      hipLaunchKernelGGL(k_sift_keep_compact, dim3(1), dim3(1024), 0, s, d_m12, d_m21, n1, cross_check, d_matches,
+                         d_count);
+    } else {
+      hipLaunchKernelGGL(k_sift_keep, dim3(div_up(n1, 256)), dim3(256), 0, s, d_m12, d_m21, n1, cross_check, sc.keep.p);
+      size_t tb = 0;
+      PCD_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, sc.keep.p, sc.pos.p, 0u, (size_t)n1, rocprim::plus<uint32_t>(), s));
+      PCD_TRY(sc.tmp.reserve(tb));
+      PCD_HIP_TRY(rocprim::exclusive_scan(sc.tmp.p, tb, sc.keep.p, sc.pos.p, 0u, (size_t)n1, rocprim::plus<uint32_t>(), s));
+      hipLaunchKernelGGL(k_sift_compact, dim3(div_up(n1, 256)), dim3(256), 0, s, d_m12, sc.keep.p, sc.pos.p, n1,
+                         d_matches, d_count);
+    }
   }
   PCD_HIP_TRY(hipGetLastError());
   return PCD_OK;

@@ -20,7 +20,7 @@ def test_reference_known_answers_on_gpu(gpu, oracle):
         assert np.array_equal(m, oracle.sift_match(d1, d2, **opt)[0]), name
 
 
-@pytest.mark.parametrize("n1,n2", [(1, 1), (127, 129), (128, 128), (300, 77), (1000, 1500)])
+@pytest.mark.parametrize("n1,n2", [(1, 1), (127, 129), (128, 128), (300, 77), (1000, 1500), (17000, 260)])
 @pytest.mark.parametrize("cross", [True, False])
 def test_random_descriptors_exact(gpu, oracle, n1, n2, cross):
     rng = np.random.default_rng(n1 * 7 + n2)
