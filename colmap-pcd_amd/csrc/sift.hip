@@ -20,6 +20,8 @@
 // (best, second, argbest) triple per descriptor goes to a partial buffer; k_sift_finalize merges the
 // partials in ascending tile order (ties -> first index, as the reference's ascending strict-> scan),
 // applies acos / max_distance / max_ratio; the cross check and the ordered compaction follow.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -189,6 +191,161 @@ __global__ __launch_bounds__(256) void k_sift_scores(const uint8_t* __restrict__
   }
 }
 
+// ---- persistent row-stripe variant -------------------------------------------------------------------
+// Workgroup (by, chunk) keeps the 128-row tile `by` of set 1 in LDS
+// and walks `ct` column tiles of set 2, whose next tile is fetched into registers while the current one is
+// multiplied and scanned (one __syncthreads per tile).  The best-of-set-2 results of the stripe's rows stay
+// in registers across the walk (one partial per chunk); the best-of-set-1 results of a column tile are
+// written per 64-row half (no cross-wave merge inside the loop).  part12 [nchunk][n1], part21 [2 nby][n2].
+__global__ __launch_bounds__(256, 2) void k_sift_scores_stripe(const uint8_t* __restrict__ d1, int n1,
+                                                            const uint8_t* __restrict__ d2, int n2,
+                                                            const int* __restrict__ sum1, const int* __restrict__ sum2,
+                                                            int4* __restrict__ part12, int4* __restrict__ part21,
+                                                            int nbx, int ct_per_chunk) {
+  __shared__ __attribute__((aligned(16))) uint8_t sA[kSiftTile * kSiftPitch];
+  __shared__ __attribute__((aligned(16))) uint8_t sB[2][kSiftTile * kSiftPitch];
+  __shared__ int sSumA[kSiftTile], sSumB[2][kSiftTile];
+  __shared__ int4 sMerge[2][64];   // [64-column half of the stripe][column]
+  const int chunk = blockIdx.x, by = blockIdx.y;
+  const int row0 = by * kSiftTile;
+  const int bx0 = chunk * ct_per_chunk, bx1 = min(bx0 + ct_per_chunk, nbx);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  if (bx0 >= bx1) return;
+
+  // ---- stage the A tile and the first B tile (re-centred to int8) ----
+  uint4 pre[4];
+  int presum = 0;
+  auto fetch_b = [&](int bx) {
+    const int col0 = bx * kSiftTile;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int c = tid + it * 256, r = c >> 3, q = c & 7;
+      pre[it] = make_uint4(0, 0, 0, 0);
+      if (col0 + r < n2) pre[it] = *reinterpret_cast<const uint4*>(d2 + (size_t)(col0 + r) * 128 + q * 16);
+    }
+    presum = (tid < kSiftTile && col0 + tid < n2) ? sum2[col0 + tid] : 0;
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int c = tid + it * 256, r = c >> 3, q = c & 7;
+      uint4 v = pre[it];
+      v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+      *reinterpret_cast<uint4*>(sB[buf] + r * kSiftPitch + q * 16) = v;
+    }
+    if (tid < kSiftTile) sSumB[buf][tid] = presum;
+  };
+  fetch_b(bx0);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = tid + it * 256, r = c >> 3, q = c & 7;
+    uint4 va = make_uint4(0, 0, 0, 0);
+    if (row0 + r < n1) va = *reinterpret_cast<const uint4*>(d1 + (size_t)(row0 + r) * 128 + q * 16);
+    va.x ^= 0x80808080u; va.y ^= 0x80808080u; va.z ^= 0x80808080u; va.w ^= 0x80808080u;
+    *reinterpret_cast<uint4*>(sA + r * kSiftPitch + q * 16) = va;
+  }
+  if (tid < kSiftTile) sSumA[tid] = row0 + tid < n1 ? sum1[row0 + tid] : 0;
+  store_b(0);
+  __syncthreads();
+
+  // running best-of-set-2 for this wave's two 32-column groups of stripe rows (true scores, global index)
+  int rb[2] = {0, 0}, rs[2] = {0, 0}, ra[2] = {-1, -1};
+
+  for (int bx = bx0; bx < bx1; ++bx) {
+    const int buf = (bx - bx0) & 1;
+    const int col0 = bx * kSiftTile;
+    if (bx + 1 < bx1) fetch_b(bx + 1);   // lands while this tile is multiplied and scanned
+
+    // accumulators start at 128 * rowsum(row): the scans need no per-element add
+    v16i acc1[2][2], acc2[2][2];   // acc1[mt][nt]: rows = set-1, cols = set-2;  acc2[nt][mt]: rows = set-2, cols = set-1
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int rr = a * 32 + (k & 3) + 8 * (k >> 2) + 4 * lh;
+        const int va = 128 * sSumA[wr * 64 + rr], vb = 128 * sSumB[buf][wc * 64 + rr];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { acc1[a][c][k] = va; acc2[a][c][k] = vb; }
+      }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      v4i fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[t] = *reinterpret_cast<const v4i*>(sA + (wr * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
+        fb[t] = *reinterpret_cast<const v4i*>(sB[buf] + (wc * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          acc1[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mt], fb[nt], acc1[mt][nt], 0, 0, 0);
+          acc2[nt][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[nt], fa[mt], acc2[nt][mt], 0, 0, 0);
+        }
+    }
+
+    // packed top-2 scans (see k_sift_scores): value = score << 8 | (255 - row in the 128-row tile)
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int ccol = (dir == 0 ? wc : wr) * 64 + ct * 32 + lr;
+        const int cconst = 128 * (dir == 0 ? sSumB[buf][ccol] : sSumA[ccol]) - kSiftConst;
+        const int other = dir == 0 ? wr : wc;
+        const int init = (int)((unsigned)(-cconst) << 8);
+        const unsigned code_base = 255u - (unsigned)(other * 64 + 4 * lh);
+        int best = init, second = init;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const v16i& acc = dir == 0 ? acc1[rt][ct] : acc2[rt][ct];
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const unsigned code = code_base - (unsigned)(rt * 32 + (reg & 3) + 8 * (reg >> 2));
+            const int v = (int)(((unsigned)acc[reg] << 8) | code);
+            int med;
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(med) : "v"(best), "v"(second), "v"(v));
+            second = med;
+            best = max(best, v);
+          }
+        }
+        {
+          const int b2 = __shfl_xor(best, 32), s2 = __shfl_xor(second, 32);
+          second = max(max(second, s2), min(best, b2));
+          best = max(best, b2);
+        }
+        const int bs = (best >> 8) + cconst, ss = (second >> 8) + cconst;        // true scores (>= 0)
+        const int arg = bs > 0 ? (dir == 0 ? row0 : col0) + 255 - (best & 255) : -1;
+        if (dir == 0) {
+          // best set-1 row (of this 64-row half of the stripe) for the tile's set-2 descriptors
+          const int gcol = col0 + ccol;
+          if (lh == 0 && gcol < n2) part21[(size_t)(by * 2 + wr) * n2 + gcol] = make_int4(bs, ss, arg, 0);
+        } else {
+          top2_merge(bs, ss, arg, rb[ct], rs[ct], ra[ct]);   // ascending tiles: ties keep the earlier index
+        }
+      }
+    }
+    if (bx + 1 < bx1) store_b(buf ^ 1);
+    __syncthreads();
+  }
+
+  // the two waves that share stripe rows (wc = 0, 1: the two 64-row halves of every column tile) merge
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+    if (wc == 1 && lh == 0) sMerge[wr][ct * 32 + lr] = make_int4(rb[ct], rs[ct], ra[ct], 0);
+  __syncthreads();
+  if (wc == 0 && lh == 0) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int4 o = sMerge[wr][ct * 32 + lr];
+      top2_merge(o.x, o.y, o.z, rb[ct], rs[ct], ra[ct]);
+      const int grow = row0 + wr * 64 + ct * 32 + lr;
+      if (grow < n1) part12[(size_t)chunk * n1 + grow] = make_int4(rb[ct], rs[ct], ra[ct], 0);
+    }
+  }
+}
+
 // sift.cc:72-104: merge the per-tile triples in ascending tile order, then the distance / ratio tests.
 // One launch for both directions: threads [0, n1) finish set 1 -> 2, threads [n1, n1 + n2) set 2 -> 1.
 __global__ __launch_bounds__(256) void k_sift_finalize(const int4* __restrict__ part12, int n1, int nbx,
@@ -300,14 +457,21 @@ struct SiftScratch {
   DevBuf<char> tmp;
 };
 static SiftScratch* g_sift[64] = {nullptr};
+static int g_sift_tile_kernel = 0;   // 1 = one 128x128 tile per workgroup (the first design; A/B timing via PCD_SIFT_TILE=1)
 static std::mutex g_sift_mu;
 
 static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uint8_t* d_d2, int n2, float max_ratio,
                               float max_distance, int cross_check, int* d_m12, int* d_m21, uint32_t* d_matches,
                               int* d_count, SiftScratch& sc, hipStream_t s) {
   const int nby = (n1 + kSiftTile - 1) / kSiftTile, nbx = (n2 + kSiftTile - 1) / kSiftTile;
+  static const int tile_env = std::getenv("PCD_SIFT_TILE") ? std::atoi(std::getenv("PCD_SIFT_TILE")) : 0;
+  g_sift_tile_kernel = tile_env;
+  // stripe walk: enough (row tile, chunk) workgroups to fill the chip twice over
+  const int nchunk = std::max(1, std::min(nbx, (512 + nby - 1) / nby));
+  const int ct_per_chunk = (nbx + nchunk - 1) / nchunk;
+  const int nchunk_used = (nbx + ct_per_chunk - 1) / ct_per_chunk;
   PCD_TRY(sc.sum1.reserve(n1)); PCD_TRY(sc.sum2.reserve(n2));
-  PCD_TRY(sc.part12.reserve((size_t)n1 * nbx)); PCD_TRY(sc.part21.reserve((size_t)n2 * nby));
+  PCD_TRY(sc.part12.reserve((size_t)n1 * std::max(nbx, nchunk_used))); PCD_TRY(sc.part21.reserve((size_t)n2 * nby * 2));
   PCD_TRY(sc.keep.reserve(n1)); PCD_TRY(sc.pos.reserve(n1));
   {
     ScopedKernelTimer t("sift_rowsum", s);
@@ -316,13 +480,18 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
   }
   {
     ScopedKernelTimer t("sift_scores", s);
-    hipLaunchKernelGGL(k_sift_scores, dim3(nbx, nby), dim3(256), 0, s, d_d1, n1, d_d2, n2, sc.sum1.p, sc.sum2.p,
-                       sc.part12.p, sc.part21.p, nbx, nby);
+    if (g_sift_tile_kernel)
+      hipLaunchKernelGGL(k_sift_scores, dim3(nbx, nby), dim3(256), 0, s, d_d1, n1, d_d2, n2, sc.sum1.p, sc.sum2.p,
+                         sc.part12.p, sc.part21.p, nbx, nby);
+    else
+      hipLaunchKernelGGL(k_sift_scores_stripe, dim3(nchunk_used, nby), dim3(256), 0, s, d_d1, n1, d_d2, n2, sc.sum1.p,
+                         sc.sum2.p, sc.part12.p, sc.part21.p, nbx, ct_per_chunk);
   }
   {
     ScopedKernelTimer t("sift_finalize", s);
-    hipLaunchKernelGGL(k_sift_finalize, dim3(div_up(((uint64_t)n1 + n2) * 16, 256)), dim3(256), 0, s, sc.part12.p, n1, nbx,
-                       sc.part21.p, n2, nby, max_ratio, max_distance, d_m12, d_m21);
+    hipLaunchKernelGGL(k_sift_finalize, dim3(div_up(((uint64_t)n1 + n2) * 16, 256)), dim3(256), 0, s, sc.part12.p, n1,
+                       g_sift_tile_kernel ? nbx : nchunk_used, sc.part21.p, n2, g_sift_tile_kernel ? nby : 2 * nby,
+                       max_ratio, max_distance, d_m12, d_m21);
   }
   {
     ScopedKernelTimer t("sift_compact", s);
