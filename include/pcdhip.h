@@ -320,7 +320,9 @@ pcd_status pcd_ba_set_parameters(pcd_ba* ba, const double* poses /*[I][7]*/, con
  *   H_img [I][6][6] g_img [I][6]   H_pt [P][3][3] g_pt [P][3]   W [O][6][3] = Jp^T JX */
 #define PCD_CAM_JAC_STRIDE 12   /* widest camera model (FULL_OPENCV, THIN_PRISM_FISHEYE) */
 typedef struct {
-  double* cost;        /* [1]  1/2 sum rho(||r_block||^2) */
+  double* cost;        /* [1]  1/2 sum rho(||r_block||^2).  Fixed-order sums, no atomics: bitwise reproducible
+                          run to run.  Requested without H_pt / g_pt it is summed per observation (the cheap
+                          LM trial-step pass), with them per track: the two agree up to summation order. */
   double* residuals;
   double* jac_q;
   double* jac_t;

@@ -87,8 +87,13 @@ def test_normal_equations_and_cost(gpu, oracle, loss):
     cp = s["image_const_pose"].astype(bool)
     assert cp.any() and not got["H_img"][cp].any() and not got["H_pt"][pc.astype(bool)].any()
     # determinism: bitwise identical on re-evaluation (fixed-order reductions, no atomics)
-    again = ba.evaluate(("cost", "H_img", "g_img"))
+    again = ba.evaluate(("cost", "H_img", "g_img", "H_pt"))
     assert again["cost"][0] == got["cost"][0] and np.array_equal(again["H_img"], got["H_img"])
+    # the cost-only pass (LM trial step) sums per observation instead of per track: same value up to the
+    # summation order, and bitwise reproducible itself
+    c1 = ba.evaluate(("cost",))["cost"][0]
+    c2 = ba.evaluate(("cost", "H_img"))["cost"][0]
+    assert c1 == c2 and abs(c1 - cost) <= 1e-11 * abs(cost)
     # parameter update path
     poses2 = s["poses"].copy(); poses2[:, 4:] += 0.01
     ba.set_parameters(poses=poses2)
