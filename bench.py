@@ -235,7 +235,7 @@ def main():
         }
         if cs:
             out["cloud_sharded"] = cs
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(xyz, nrm, q, mr, scene, min(a.cpu_sample_queries, Q),
                                                min(a.cpu_sample_points, P))
         print(json.dumps(out))
