@@ -220,3 +220,15 @@ def test_full_size_properties(gpu):
         ks.append(kk.clone())
         cs.close()
     assert torch.equal(torch.minimum(ks[0], ks[1]), keys[:Qs])
+
+
+@pytest.mark.parametrize("offset", [1e3, 1e5, 3e6])
+def test_far_from_origin(gpu, offset):
+    """coordinates with few mantissa bits left for the cell arithmetic (float spacing 0.25 m at 3e6): the
+    binning slack sends more queries to the exact fallback, the result stays bit-exact"""
+    xyz, nrm = synth.cloud_planes(300_000, seed=3)
+    xyz = (xyz.astype(np.float64) + offset).astype(np.float32)
+    q = synth.queries(xyz, 30_000, seed=4)
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    _check_exact(c.nn(q), c.nn(q, gpu.NN_BRUTEFORCE), f"grid vs brute force at offset {offset}")
+    c.close()
