@@ -73,13 +73,15 @@ __global__ void k_associate(const float4* __restrict__ pts4, const float4* __res
   float p[3] = {0, 0, 0}, nv[3] = {0, 0, 0};
   uint32_t gi = (uint32_t)key;
   if (found) {
+    // same ownership test as k_winner_payload: a key another shard won (e.g. after a cross-rank MIN)
+    // must not be mapped onto one of this shard's rows
     const uint64_t li = (uint64_t)(gi - index_base) / index_stride;
-    if (li < n) {
+    if (gi >= index_base && (gi - index_base) % index_stride == 0 && li < n) {
       const float4 a = pts4[li], b = nrm4[li];
       p[0] = a.x; p[1] = a.y; p[2] = a.z;
       nv[0] = b.x; nv[1] = b.y; nv[2] = b.z;
     } else {
-      found = false;  // key of another shard: use the payload path instead
+      found = false;  // key of another shard: no association here, use the payload path instead
     }
   }
   const double X[3] = {q[3 * i], q[3 * i + 1], q[3 * i + 2]};

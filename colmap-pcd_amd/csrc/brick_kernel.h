@@ -33,7 +33,13 @@ namespace pcd {
 #endif
 constexpr int kTile = PCD_KTILE;
 static_assert(kTile == 256, "a tile is 4 DMA instructions (128/192-point tiles were measured slower and removed)");
-constexpr int kAblateCompare = 0x100, kAblateDma = 0x200, kAblateReduce = 0x400, kAblateFallback = 0x800, kAblateTiles = 0x1000;
+// timing-only ablations (results are then wrong): compiled in only with -DPCD_ABLATE (tools/nn_ablate.py builds
+// such a variant); in the shipped library the masks are 0 and every `flags & kAblate*` folds away.
+#ifdef PCD_ABLATE
+constexpr int kAblateCompare = 0x100, kAblateReduce = 0x400, kAblateFallback = 0x800, kAblateTiles = 0x1000;
+#else
+constexpr int kAblateCompare = 0, kAblateReduce = 0, kAblateFallback = 0, kAblateTiles = 0;
+#endif
 
 __device__ __forceinline__ void lds_dma16(const float4* gsrc, float4* lds_wave_base) {
   // LDS destination = wave-uniform base + lane * 16 (hardware adds the lane offset)
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
                                                   const uint4* __restrict__ items, NnCounters* __restrict__ ctr,
                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ fb_list,
                                                   int flags) {
-  // flags: bit 0 = collect statistics; bits 8.. = timing-only ablations (results are then wrong)
+  // flags: bit 0 = collect statistics (bits 8.. = ablations, only in -DPCD_ABLATE builds)
   const int collect_stats = flags & 1;
   static_assert(G == 8, "the transposed reduction is written for 8 queries per group");
   __shared__ __attribute__((aligned(16))) float4 s_tile[4][2][kTile];

@@ -534,7 +534,11 @@ pcd_status pcd_nn_last_stats(pcd_cloud* c, pcd_nn_stats* st) {
 pcd_status pcd_nn_set_tuning(int brick_cells, int halo_cells, int collect_stats) {
   if (brick_cells > 0) g_brick_B = brick_cells;
   if (halo_cells >= 0) g_brick_R = halo_cells;
+#ifdef PCD_ABLATE
   g_collect_stats = collect_stats;
+#else
+  g_collect_stats = collect_stats & 1;   // the ablation bits exist only in -DPCD_ABLATE builds
+#endif
   return PCD_OK;
 }
 

@@ -93,6 +93,7 @@ class PointCloudProcess {
     pcd_proj_.reset();
     pcd_cloud_destroy(cloud_);
     cloud_ = nullptr;
+    host_nrm_.clear();   // cached normals belong to the old cloud
     return pcd_cloud_create(xyz, nrm, n, &o, &cloud_) == PCD_OK;
   }
 

@@ -10,6 +10,8 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 #include <string>
@@ -78,6 +80,17 @@ inline bool ReadPlyXYZNormal(const std::string& path, std::vector<float>* xyz, s
     else if (n == "normal_z" || n == "nz") slot[5] = (int)i;
   }
   if (slot[0] < 0 || slot[1] < 0 || slot[2] < 0) { std::fclose(f); return false; }
+  // a corrupt header must not drive the allocation: the vertex data cannot be larger than what is left of the
+  // file (binary: stride bytes per vertex; ascii: at least "0 " per property)
+  {
+    const long body = std::ftell(f);
+    if (body < 0 || std::fseek(f, 0, SEEK_END) != 0) { std::fclose(f); return false; }
+    const long end = std::ftell(f);
+    if (end < body || std::fseek(f, body, SEEK_SET) != 0) { std::fclose(f); return false; }
+    const size_t left = (size_t)(end - body);
+    const size_t min_per_vertex = binary ? (size_t)stride : 2 * props.size();
+    if (min_per_vertex == 0 || nverts > left / min_per_vertex) { std::fclose(f); return false; }
+  }
   xyz->assign(3 * nverts, 0.f);
   nrm->assign(3 * nverts, 0.f);
   auto as_float = [](const std::string& t, const unsigned char* p) -> float {
@@ -108,15 +121,14 @@ inline bool ReadPlyXYZNormal(const std::string& path, std::vector<float>* xyz, s
   } else {
     for (size_t i = 0; i < nverts && ok; ++i) {
       if (!std::fgets(line, sizeof line, f)) { ok = false; break; }
-      std::istringstream is(line);
+      // every token goes through strtod: it reads "nan", "-inf", "-nan" with their sign, which operator>>
+      // does not (it fails on them after consuming the '-')
+      const char* cur = line;
       for (size_t p = 0; p < props.size(); ++p) {
-        double v;
-        if (!(is >> v)) {
-          std::string w;              // "nan" / "inf" tokens are not parsed by operator>> on all libstdc++
-          is.clear();
-          if (!(is >> w)) { ok = false; break; }
-          v = std::strtod(w.c_str(), nullptr);
-        }
+        char* endp = nullptr;
+        const double v = std::strtod(cur, &endp);
+        if (endp == cur) { ok = false; break; }   // too few / unparsable tokens on the line
+        cur = endp;
         for (int k = 0; k < 6; ++k)
           if (slot[k] == (int)p) (k < 3 ? (*xyz)[3 * i + k] : (*nrm)[3 * i + k - 3]) = (float)v;
       }

@@ -253,6 +253,31 @@ static void TestPlyReader() {
   }
   std::vector<float> a, b;
   CHECK(!ReadPlyXYZNormal("/tmp/pcdhip_does_not_exist.ply", &a, &b));   // load failure -> false (ply.cc:14-17)
+  {  // ascii: signed non-finite tokens keep their sign; a header that promises more vertices than the file
+     // can hold is a failed load, not an allocation of that size
+    const std::string p = "/tmp/pcdhip_test_tokens.ply";
+    const char* hdr = "ply\nformat ascii 1.0\nelement vertex %s\nproperty float x\nproperty float y\nproperty float z\n"
+                      "property float normal_x\nproperty float normal_y\nproperty float normal_z\nend_header\n";
+    FILE* f = std::fopen(p.c_str(), "wb");
+    std::fprintf(f, hdr, "2");
+    std::fprintf(f, "-inf 1 2 -nan 0 1\n3 inf -0.5 0 nan 1e-3\n");
+    std::fclose(f);
+    CHECK(ReadPlyXYZNormal(p, &a, &b));
+    CHECK_EQ(a.size(), 6u);
+    CHECK(a.size() == 6 && std::isinf(a[0]) && a[0] < 0 && a[1] == 1.f && std::isnan(b[0]) && std::isinf(a[4]) && a[4] > 0 &&
+          a[5] == -0.5f && std::isnan(b[4]) && b[5] == 1e-3f);
+    f = std::fopen(p.c_str(), "wb");
+    std::fprintf(f, hdr, "4000000000000");
+    std::fprintf(f, "0 0 0 0 0 1\n");
+    std::fclose(f);
+    CHECK(!ReadPlyXYZNormal(p, &a, &b));
+    f = std::fopen(p.c_str(), "wb");
+    std::fprintf(f, hdr, "2");
+    std::fprintf(f, "0 0 0 0 0 1\n1 2 3\n");    // short row
+    std::fclose(f);
+    CHECK(!ReadPlyXYZNormal(p, &a, &b));
+    std::remove(p.c_str());
+  }
 }
 
 // SiftMatchGPU-shaped adapter on the hand-made descriptors of feature/sift_test.cc (two unit descriptors each:

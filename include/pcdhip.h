@@ -152,7 +152,9 @@ pcd_status pcd_associate(pcd_cloud* c, const double* q_xyz, uint64_t Q, const do
 
 /* Device form: every pointer in `out` and d_q_xyz / d_max_range are device
  * pointers.  d_keys_in == NULL: run the search; otherwise use these keys
- * (e.g. after a cross-rank MIN) and skip the search. */
+ * (e.g. after a cross-rank MIN) and skip the search.  On a sharded cloud
+ * (index_stride != 1 or index_base != 0) a key whose index this shard does not
+ * own yields type 0 here: the owner associates it, or use the payload path. */
 pcd_status pcd_associate_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q, const double* d_max_range,
                                 uint64_t max_range_count, int gate_mode, const uint64_t* d_keys_in,
                                 const pcd_assoc_out* d_out, void* stream);

@@ -7,7 +7,7 @@
  *
  * PARITY STATUS: "parity unpinned" by the reference (src/lidar and the
  * association loops have no tests); pinned by closed-form checks in
- * tests/test_oracle_assoc.py (hand-computed cases) and by numpy float64
+ * tests/test_oracle_cpu.py (hand-computed cases) and by numpy float64
  * re-derivation.
  *
  * Reference lines followed:

@@ -10,7 +10,7 @@
  * installed, so the reference cannot be built here.  The restatement is
  * pinned instead by (1) the published FLANN L2_Simple<float> arithmetic,
  * (2) agreement brute-force <-> exact KD-tree below, (3) scipy cKDTree
- * on float32-representable inputs (tests/test_oracle_nn.py).
+ * on float32-representable inputs (tests/test_oracle_cpu.py).
  *
  * Reference lines followed:
  *   src/lidar/ply.cc:33-57    PointCloudDirectionTrans (axis swap, NaN rows dropped)

@@ -14,7 +14,7 @@
 //                                 L2-normalise, round(512 x) truncated to uint8)  -- restated to regenerate
 //                                 the inputs of the reference's known-answer tests (:296-428)
 // PARITY STATUS: pinned by the reference's own expected match counts 2 / 50 / 50,48,49 / 50,48
-// (tests/test_oracle_cpu.py::test_sift_reference_known_answers).
+// (tests/test_sift_cpu.py::test_sift_reference_known_answers).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>

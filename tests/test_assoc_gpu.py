@@ -100,3 +100,41 @@ def test_sharded_cloud_min_and_payload(gpu, oracle):
     _compare(out, out6, ok, exp, 0)
     for s in shards:
         s.close()
+
+
+def test_associate_device_ignores_foreign_keys(gpu, oracle):
+    """pcd_associate_device with MIN-combined keys on a 2-shard cloud: a shard associates only the keys it owns
+    (index_base + i*stride); keys another shard won give type 0 there, never a row of this shard.
+    The two shards' outputs together equal the single-cloud association."""
+    import torch
+    xyz, nrm = synth.cloud_planes(20000, seed=13, patches=8)
+    q = synth.queries(xyz, 3000, seed=14)
+    Q = q.shape[0]
+    shards = [gpu.Cloud(xyz[s::2], nrm[s::2], raw_lidar_frame=False, index_base=s, index_stride=2) for s in range(2)]
+    dq = torch.from_numpy(q).cuda()
+    keys = [torch.empty(Q, dtype=torch.int64, device="cuda") for _ in range(2)]
+    for s in range(2):
+        shards[s].nn_device(dq, Q, keys[s])
+    kmin = torch.minimum(keys[0], keys[1])
+    mr = torch.full((1,), 1.0, dtype=torch.float64, device="cuda")
+    outs = []
+    for s in range(2):
+        d = {n: torch.zeros(sh, dtype=t, device="cuda") for n, sh, t in
+             [("lidar_xyz", (Q, 3), torch.float64), ("abcd", (Q, 4), torch.float64), ("type", (Q,), torch.uint8),
+              ("dist", (Q,), torch.float64), ("angle", (Q,), torch.float64), ("dist2plane", (Q,), torch.float64)]}
+        shards[s].associate_device(dq, Q, mr, 1, 0, d, kmin)
+        torch.cuda.synchronize()
+        outs.append({n: v.cpu().numpy() for n, v in d.items()})
+    idx, sq, found = oracle.nn_bruteforce(xyz, q)
+    out6, ok = oracle.search_nearest_neibor(xyz, nrm, idx, found)
+    exp = oracle.associate(q, out6, ok, 1.0, 0)
+    owner = idx % 2
+    for s in range(2):
+        foreign = owner != s
+        assert (outs[s]["type"][foreign] == 0).all(), "a foreign key was associated with a local row"
+        assert (outs[s]["abcd"][foreign] == 0).all()
+    merged = {n: np.where((owner == 0).reshape((-1,) + (1,) * (outs[0][n].ndim - 1)), outs[0][n], outs[1][n])
+              for n in outs[0]}
+    _compare(merged, out6, ok, exp, 0)
+    for s in shards:
+        s.close()

@@ -1,4 +1,6 @@
-"""timing-only ablations of k_nn_brick (results are wrong while a flag is set): python tools/nn_ablate.py"""
+"""timing-only ablations of k_nn_brick (results are wrong while a flag is set).  Needs a variant of the library
+built with -DPCD_ABLATE (the shipped one has no ablation branches):
+  PCDHIP_LIB=colmap-pcd_amd/variants/libpcdhip_ablate.so python tools/nn_ablate.py"""
 import os
 import sys
 
