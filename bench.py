@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- colmap-pcd registration hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic input:
-  1. exact NN association of Q = 1 M 3D feature points against the N = 10 M-point LiDAR cloud
+One "step" = one pass of the hot path over the metric workload M of BASELINE.json / SURVEY.md section 8d
+(10 M-point LiDAR cloud, 1 M 3D feature points, one BA scene of 1000 cameras / 1 M tracks / ~5 M observations /
+0.9 M LiDAR terms, OPENCV):
+  1. exact NN association of the feature points against the cloud
      (replaces the serial KD-tree loops, lidar/kdtree.cc:10-21 via controllers/bundle_adjustment.cc:130-185),
   2. the fused plane-association epilogue (lidar/lidar_point.cc, optim/bundle_adjustment.cc:358-410),
-  3. one bundle-adjustment iteration's worth of evaluation on a 1000-camera / 1 M-point / ~5 M-observation
-     OPENCV scene: residuals + Jacobians + per-image / per-point J^T J, J^T r blocks + cost, then one
-     residual-only (cost) pass (what ceres::Solve asks of the cost functions per LM iteration).
-Inputs are resident in HBM before the timed region.  value = feature points taken through the whole step
-per second, summed over all ranks; nn_queries_per_sec and ba_iter_ms are reported beside it.
+  3. one bundle-adjustment iteration's worth of evaluation (section 8d: one evaluate WITH Jacobians + one
+     residual-only evaluate): normal-equation mode -- cost, per-image 6x6 + 6 blocks, per-point 3x3 + 3 blocks
+     and the 6x3 pose-point coupling block W of every observation (everything a Schur complement needs) --
+     then the cost-only pass of the LM trial step.
+Inputs are resident in HBM before the timed region.  value = feature points taken through the whole step per
+second (whole job); nn_queries_per_sec and ba_iter_ms are reported beside it.  The Ceres route (raw mode:
+residuals + ambient Jacobian blocks of every residual block, then a residual-only pass) is timed after the main
+region and reported as ba_raw_iter_ms.
 
-N > 1 (one process per GPU, torch.distributed / RCCL): weak scaling -- every rank holds the whole cloud
-(160 MB of 288 GB) and its own 1 M queries and its own 1 M-point track shard of the BA scene; the BA
-camera blocks are combined with one RCCL all-reduce (sum, f64) per evaluation.  The cloud-sharded NN
-variant (interleaved shards, RCCL all-reduce MIN on the packed per-query keys + SUM of the winner
-payload) is timed after the main region and reported under "cloud_sharded".
+N > 1 (one process per GPU, torch.distributed / RCCL): STRONG scaling of the same workload -- the cloud is
+replicated (160 MB of 288 GB), the 1 M queries are split into N contiguous ranges and the BA scene into N track
+shards (a rank owns points p = rank mod N with all their observations and LiDAR terms, so point blocks and W are
+complete locally); the per-image blocks are partial sums: one RCCL all-reduce (sum, f64) of I*42 doubles per
+Jacobian pass and one of the cost per pass.  No collective on the NN path.  The cloud-sharded NN variant of
+north_star (spatially compact shards, all-reduce MIN on the packed per-query keys) is timed after the main
+region and reported under "cloud_sharded".
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,10 +40,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import pcdhip  # noqa: E402
+from pcdhip import dist as pdist  # noqa: E402
 from pcdhip import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-REC_BYTES = 16                   # staged cloud record {x,y,z,index}
+POINT_BYTES = 12                 # xyz fp32 per staged cloud point
+REC_BYTES = 16                   # what the layout actually streams: {x,y,z,index} records
 PER_QUERY_BYTES = 20             # 12 B query in + 8 B key out
 
 
@@ -50,41 +60,78 @@ def parse():
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-queries", type=int, default=1_000_000)   # ~2.5 s of one core
-    ap.add_argument("--cpu-sample-points", type=int, default=600_000)      # ~10 s of one core
+    ap.add_argument("--cpu-sample-points", type=int, default=200_000)      # ~3 s of one core (Jets)
     ap.add_argument("--no-cloud-sharded", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the raw-mode / e2e / config-A legs")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path)")
     return ap.parse_args()
 
 
+def source_hash():
+    """hash of the NN kernel sources: profiles/traffic.json is only quoted when it was measured on these"""
+    h = hashlib.sha256()
+    for f in ("nn.hip", "brick_kernel.h", "grid.h", "cloud.hip"):
+        with open(os.path.join(ROOT, "colmap-pcd_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(xyz, nrm, q, mr, scene, nq, npts):
-    """oracle ("port") timed on this host, single thread like the reference's serial loops."""
+    """The oracle ("port") timed on this host.  The reference's NN loops are serial and its Ceres evaluation uses
+    all cores once the problem has >= 50 000 residuals (optim/bundle_adjustment.cc:515-530): both threadings are
+    timed, for NN and for the Jet evaluation; `value` is the all-cores figure, the others are listed beside it."""
     from oracle import pyoracle as po
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     t0 = time.time()
     kd = po.KDTree(xyz)                      # FLANN-style single tree, leaf 15
     t_build = time.time() - t0
     qs = q[:nq]
-    t0 = time.time()
-    idx, sq, found = kd.query(qs)
-    out6, ok = po.search_nearest_neibor(xyz, nrm, idx, found)
-    po.associate(qs, out6, ok, mr[:nq], po.GATE_MAPPER_LOCAL)
-    t_nn = time.time() - t0
-    # BA: the tracks of the first npts points
-    sel = scene["obs_point"] < npts
-    lsel = scene["lidar_point"] < npts
-    sub = dict(scene)
-    sub["points"] = scene["points"][:npts]
-    sub["obs_image"], sub["obs_point"], sub["obs_xy"] = scene["obs_image"][sel], scene["obs_point"][sel], scene["obs_xy"][sel]
-    sub["lidar_point"], sub["lidar_abcd"], sub["lidar_weight"] = scene["lidar_point"][lsel], scene["lidar_abcd"][lsel], scene["lidar_weight"][lsel]
-    ob = po.BA(**sub)
-    t0 = time.time()
-    ob.normal_equations()                    # residual + Jacobian (Jet autodiff) + blocks
-    ob.evaluate_raw()                        # stands in for the residual-only pass (upper bound: also fills J)
-    t_ba = time.time() - t0
-    per_point = t_nn / nq + t_ba / npts
-    return dict(value=1.0 / per_point, unit="queries/s", cores=1, kind="port",
-                sample=f"kd-tree over the full {xyz.shape[0]}-pt cloud (build {t_build:.1f}s, not counted), {nq} queries "
-                       f"NN+association {t_nn:.2f}s; BA Jet evaluation of {npts} tracks / {int(sel.sum())} obs {t_ba:.2f}s",
-                nn_queries_per_sec=nq / t_nn, ba_iter_ms_full_scene=t_ba / npts * scene["points"].shape[0] * 1e3)
+
+    def nn_pass(threads):
+        t0 = time.time()
+        idx, sq, found = kd.query(qs) if threads == 1 else kd.query_mt(qs, threads)
+        out6, ok = po.search_nearest_neibor(xyz, nrm, idx, found)
+        po.associate(qs, out6, ok, mr[:nq], po.GATE_MAPPER_LOCAL)
+        return time.time() - t0
+    t_nn1 = nn_pass(1)
+    t_nnc = nn_pass(cores)
+
+    def sub_scene(n):
+        sel = scene["obs_point"] < n
+        lsel = scene["lidar_point"] < n
+        sub = dict(scene)
+        sub["points"] = scene["points"][:n]
+        sub["obs_image"], sub["obs_point"], sub["obs_xy"] = scene["obs_image"][sel], scene["obs_point"][sel], scene["obs_xy"][sel]
+        sub["lidar_point"], sub["lidar_abcd"], sub["lidar_weight"] = scene["lidar_point"][lsel], scene["lidar_abcd"][lsel], scene["lidar_weight"][lsel]
+        return po.BA(**sub), int(sel.sum())
+    P = scene["points"].shape[0]
+    # one Ceres LM iteration's evaluation = every block's Evaluate with Jacobians (Jets) + once without
+    ob1, nobs1 = sub_scene(npts)
+    t0 = time.time(); ob1.evaluate_mt(1, True); ob1.evaluate_mt(1, False); t_ba1 = time.time() - t0
+    nptc = min(P, npts * min(cores, 8))
+    obc, nobsc = sub_scene(nptc)
+    t0 = time.time(); obc.evaluate_mt(cores, True); obc.evaluate_mt(cores, False); t_bac = time.time() - t0
+    per_point = lambda tnn, tba, n: tnn / nq + tba / n
+    v_all = 1.0 / per_point(t_nnc, t_bac, nptc)
+    return dict(value=v_all, unit="queries/s", cores=cores, kind="port",
+                sample=f"kd-tree over the full {xyz.shape[0]}-pt cloud (build {t_build:.1f}s, not counted); {nq} queries "
+                       f"NN+association: {t_nn1:.2f}s on 1 thread, {t_nnc:.2f}s on {cores}; BA Jet evaluation + "
+                       f"residual-only pass: {npts} tracks / {nobs1} obs {t_ba1:.2f}s on 1 thread, "
+                       f"{nptc} tracks / {nobsc} obs {t_bac:.2f}s on {cores}",
+                nn_queries_per_sec=nq / t_nnc, ba_iter_ms_full_scene=t_bac / nptc * P * 1e3,
+                single_thread=dict(cores=1, value=1.0 / per_point(t_nn1, t_ba1, npts), nn_queries_per_sec=nq / t_nn1,
+                                   ba_iter_ms_full_scene=t_ba1 / npts * P * 1e3),
+                reference_threading=dict(note="NN serial (as the reference's loops), BA on all cores (as its Ceres options)",
+                                         value=1.0 / per_point(t_nn1, t_bac, nptc)))
+
+
+def timed(fn, steps, sync):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / steps
 
 
 def main():
@@ -106,40 +153,49 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     # ------------------------------------------------------------ inputs (seeded) ---
+    # ONE workload for every N: the same cloud, queries and scene on every rank; rank r works on its share.
     xyz, nrm = synth.cloud_planes(a.cloud)
-    q = synth.queries(xyz, a.queries, seed=99 + rank)            # every rank its own batch (weak scaling)
-    mr = synth.max_range_schedule(a.queries, seed=5 + rank)
-    scene = synth.ba_scene(a.cams, a.points, seed=11 + rank)
-    Q = a.queries
+    q_all = synth.queries(xyz, a.queries, seed=99)
+    mr_all = synth.max_range_schedule(a.queries, seed=5)
+    scene = synth.ba_scene(a.cams, a.points, seed=11, order="image")   # observations in AddImageToProblem order
+    Qtot = a.queries
+    qlo, qhi = pdist.shard_range(Qtot, rank, world)
+    q, mr = q_all[qlo:qhi], mr_all[qlo:qhi]
+    Q = qhi - qlo
+    my_scene = scene if world == 1 else pdist.shard_tracks(scene, rank, world)[0]
     cloud = pcdhip.Cloud(xyz, nrm, device=local_rank, raw_lidar_frame=False)
-    ba = pcdhip.BA(**scene, device=local_rank)
+    ba = pcdhip.BA(**my_scene, device=local_rank)
     I, P, O, L = ba.I, ba.P, ba.O, ba.L
+    Ptot, Otot, Ltot = scene["points"].shape[0], len(scene["obs_image"]), len(scene["lidar_point"])
 
-    dq = torch.from_numpy(q).to(dev)
-    dmr = torch.from_numpy(mr).to(dev)
-    keys = torch.empty(Q, dtype=torch.int64, device=dev)
-    aout = dict(lidar_xyz=torch.empty(Q, 3, dtype=torch.float64, device=dev),
-                abcd=torch.empty(Q, 4, dtype=torch.float64, device=dev),
-                type=torch.empty(Q, dtype=torch.uint8, device=dev),
-                dist=torch.empty(Q, dtype=torch.float64, device=dev),
-                angle=torch.empty(Q, dtype=torch.float64, device=dev))
-    img_blocks = torch.empty(I * 42, dtype=torch.float64, device=dev)   # [I][36] H then [I][6] g, one all-reduce
-    H_img, g_img = img_blocks[: I * 36], img_blocks[I * 36:]
-    H_pt = torch.empty(P, 9, dtype=torch.float64, device=dev)
-    g_pt = torch.empty(P, 3, dtype=torch.float64, device=dev)
-    cost = torch.empty(2, dtype=torch.float64, device=dev)
-    full = dict(cost=cost[0:1], H_img=H_img, g_img=g_img, H_pt=H_pt, g_pt=g_pt)
-    resid_only = dict(cost=cost[1:2])
+    dq = torch.from_numpy(np.ascontiguousarray(q)).to(dev)
+    dmr = torch.from_numpy(np.ascontiguousarray(mr)).to(dev)
+    keys = torch.empty(max(Q, 1), dtype=torch.int64, device=dev)
+    f64 = lambda *s: torch.empty(*s, dtype=torch.float64, device=dev)
+    aout = dict(lidar_xyz=f64(max(Q, 1), 3), abcd=f64(max(Q, 1), 4),
+                type=torch.empty(max(Q, 1), dtype=torch.uint8, device=dev), dist=f64(max(Q, 1)), angle=f64(max(Q, 1)))
+    img_blocks = f64(I * 42 + 1)                           # [I][36] H, [I][6] g, cost: ONE all-reduce per Jacobian pass
+    H_img, g_img, cost_j = img_blocks[: I * 36], img_blocks[I * 36: I * 42], img_blocks[I * 42:]
+    H_pt, g_pt, W = f64(P, 9), f64(P, 3), f64(max(O, 1), 18)
+    cost_r = f64(1)
+    full = dict(cost=cost_j, H_img=H_img, g_img=g_img, H_pt=H_pt, g_pt=g_pt, W=W)
+    resid_only = dict(cost=cost_r)
 
-    def step():
+    def nn_step():
         cloud.nn_device(dq, Q, keys, pcdhip.NN_AUTO, stream)
         cloud.associate_device(dq, Q, dmr, Q, pcdhip.GATE_MAPPER_LOCAL, aout, keys, stream)
+
+    def ba_step():
         ba.evaluate_device(full, stream)
         if world > 1:
-            dist.all_reduce(img_blocks)           # RCCL sum over xGMI: camera J^T J / J^T r blocks
+            dist.all_reduce(img_blocks)       # RCCL sum over xGMI: camera J^T J / J^T r blocks + cost
         ba.evaluate_device(resid_only, stream)
         if world > 1:
-            dist.all_reduce(cost)
+            dist.all_reduce(cost_r)
+
+    def step():
+        nn_step()
+        ba_step()
 
     def sync():
         if world > 1:
@@ -171,73 +227,82 @@ def main():
     dt = float(tmax.item())
     ms_per_step = dt / a.steps * 1e3
 
+    extras = {}
+    if not a.no_extras:
+        # ---- Ceres route: raw residual + Jacobian blocks, then a residual-only pass (residual vector) ----
+        raw = dict(residuals=f64(2 * O + L), jac_q=f64(max(O, 1), 8), jac_t=f64(max(O, 1), 6), jac_X=f64(max(O, 1), 6),
+                   jac_lidar=f64(max(L, 1), 3))
+        res_only = dict(residuals=raw["residuals"])
+
+        def raw_step():
+            ba.evaluate_device(raw, stream)
+            ba.evaluate_device(res_only, stream)
+        for _ in range(2):
+            raw_step()
+        t_raw = timed(raw_step, a.steps, sync)
+        t_nn = timed(nn_step, a.steps, sync)
+        t_ba = timed(ba_step, a.steps, sync)
+        extras.update(ba_raw_iter_ms=t_raw * 1e3, nn_wall_ms=t_nn * 1e3, ba_wall_ms=t_ba * 1e3)
+        del raw, res_only
+
     # ------------------------------------------------- cloud-sharded NN (north_star's collective) ---
     cs = None
-    if world > 1 and not a.no_cloud_sharded:
-        shard = pcdhip.Cloud(xyz[rank::world], nrm[rank::world], device=local_rank, raw_lidar_frame=False,
-                             index_base=rank, index_stride=world)
-        q0 = torch.from_numpy(synth.queries(xyz, Q, seed=99)).to(dev)    # same queries on every rank
-        payload = torch.empty(Q, 6, dtype=torch.int32, device=dev)
-
-        def cs_step():
-            shard.nn_device(q0, Q, keys, pcdhip.NN_AUTO, stream)
-            dist.all_reduce(keys, op=dist.ReduceOp.MIN)                  # packed (distance, index) keys
-            shard.winner_payload_device(keys, Q, payload, stream)
-            dist.all_reduce(payload)                                     # bit patterns, one owner each
-            pcdhip.associate_from_payload_device(local_rank, q0, Q, dmr, Q, pcdhip.GATE_MAPPER_LOCAL, keys, payload,
-                                                 aout, stream)
-        for _ in range(2):
-            cs_step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            cs_step()
-        sync()
-        tc = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-        cs = dict(ms_per_step=float(tc.item()) / a.steps * 1e3, queries_per_sec=Q / (float(tc.item()) / a.steps),
-                  scaling="strong", note="one 10M cloud in N interleaved shards, same 1M queries on every rank")
-        shard.close()
+    if world > 1 and not a.no_cloud_sharded and hasattr(pdist, "bench_cloud_sharded"):
+        cs = pdist.bench_cloud_sharded(xyz, nrm, q_all, mr_all, rank, world, local_rank, dev, stream, a.steps, sync)
 
     if rank == 0:
         per = {k: ms / n for k, (n, ms) in prof.items()}                       # average per launch
         nn_ms = sum(ms for k, (n, ms) in prof.items() if k.startswith("nn_") or k == "associate") / a.steps
         ba_ms = sum(ms for k, (n, ms) in prof.items() if k.startswith("ba_")) / a.steps   # per step (both passes)
         brick_ms = per.get("nn_brick", float("nan"))
-        staged = st["staged_points"] - 0
-        alg_bytes = staged * REC_BYTES + PER_QUERY_BYTES * Q
+        staged = st["staged_points"]
+        alg_bytes = staged * POINT_BYTES + PER_QUERY_BYTES * Q
         achieved = alg_bytes / (brick_ms * 1e-3) / 1e9
-        traffic = None
+        rec_achieved = (staged * REC_BYTES + PER_QUERY_BYTES * Q) / (brick_ms * 1e-3) / 1e9
+        traffic, hbm_frac, tnote = None, None, "profiles/traffic.json absent"
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
-            traffic = json.load(open(tp)).get("nn_brick_bytes_per_launch")
+            tj = json.load(open(tp))
+            if tj.get("source_hash") == source_hash() and tj.get("workload") == [a.cloud, Qtot] and world == 1:
+                traffic = tj.get("nn_brick_bytes_per_launch")
+                hbm_frac = traffic / (brick_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                tnote = "PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from tools/prof_bench.sh on these kernel sources"
+            else:
+                tnote = "profiles/traffic.json was measured on other kernel sources / another workload: not quoted"
         out = {
             "metric": "NN queries/sec + BA-iter ms, 10M-pt cloud / 1M 3D feats",
-            "value": world * Q / (dt / a.steps),
+            "value": Qtot / (dt / a.steps),
             "unit": "queries/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 (NN distances) / f64 (association, BA)", "data": "synthetic",
-            "config": {"workload": "M: 10M-pt 'planes' cloud / 1M queries per GPU + BA scene "
-                                   f"{a.cams} cams / {P} pts / {O} obs / {L} lidar terms (OPENCV)",
-                       "cloud_points": a.cloud, "queries_per_gpu": Q, "parallelism":
-                       "single GPU" if world == 1 else f"cloud replicated, queries + tracks sharded x{world}, "
-                       "RCCL all-reduce of camera blocks"},
-            "nn_queries_per_sec": world * Q / (nn_ms * 1e-3),
+            "config": {"workload": f"M: {a.cloud}-pt 'planes' cloud / {Qtot} queries + BA scene "
+                                   f"{a.cams} cams / {Ptot} pts / {Otot} obs / {Ltot} lidar terms (OPENCV), "
+                                   "the same total at every N",
+                       "cloud_points": a.cloud, "queries": Qtot, "queries_this_rank": Q, "parallelism":
+                       "single GPU" if world == 1 else f"cloud replicated, queries + tracks split x{world}, "
+                       "RCCL all-reduce of camera blocks + cost"},
+            "nn_queries_per_sec": Q / (nn_ms * 1e-3) * world,
             "ba_iter_ms": ba_ms,
+            "ba_iter_def": "normal-equation pass (cost, H_img, g_img, H_pt, g_pt, W) + cost-only pass, kernel time of rank 0",
             "kernel_ms": {k: round(v, 4) for k, v in sorted(per.items())},
             "roofline": {"bound": "hbm", "kernel": "k_nn_brick", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes": alg_bytes, "launch_ms": brick_ms,
+                         "hbm_frac": hbm_frac, "traffic_note": tnote,
+                         "algorithmic_bytes": alg_bytes, "bytes_per_staged_point": POINT_BYTES,
+                         "frac_16B_records": rec_achieved / HBM_PEAK_GBS, "launch_ms": brick_ms,
                          "staged_points": staged, "brick_groups": st["brick_groups"],
-                         "fallback_queries": st["fallback_queries"],
-                         "compulsory_bytes": 12 * a.cloud + PER_QUERY_BYTES * Q},
+                         "fallback_queries": st["fallback_queries"], "pair_evals": st["pair_evals"],
+                         "compulsory_bytes": 12 * a.cloud + PER_QUERY_BYTES * Q,
+                         "note": "the kernel is VALU-bound, not HBM-bound (DESIGN.md section 5): frac is SURVEY 8d's "
+                                 "algorithmic figure, hbm_frac the measured HBM share; compare kernels by launch_ms"},
         }
+        out.update(extras)
         if cs:
             out["cloud_sharded"] = cs
         if not a.no_cpu_baseline and world == 1:   # reported at N = 1 only (rank 0's host cores)
-            out["cpu_baseline"] = cpu_baseline(xyz, nrm, q, mr, scene, min(a.cpu_sample_queries, Q),
-                                               min(a.cpu_sample_points, P))
+            out["cpu_baseline"] = cpu_baseline(xyz, nrm, q_all, mr_all, scene, min(a.cpu_sample_queries, Qtot),
+                                               min(a.cpu_sample_points, Ptot))
         print(json.dumps(out))
     cloud.close()
     ba.close()

@@ -46,6 +46,7 @@ struct BaDev {
   const uint32_t* pt_lidar_start; const uint32_t* pt_lidar_list;
   const uint32_t* img_obs_start;  // [I+1]
   const int* img_pt;              // [O] point of the e-th observation of the image-major order
+  const uint32_t* img_obs;        // [O] its index in the caller's observation order (W is written there)
   const double* img_xy;           // [O][2]
   int I, P, nslices; uint64_t O, L;
   int loss_type; double loss_scale;
@@ -195,8 +196,14 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
 }
 
 // ------------------------------------------------------------- images ------
-template <int MODEL>
-__global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__ Himg, double* __restrict__ gimg) {
+// WANT_W: also write the pose-point coupling block W[o] = Jp^T JX (6x3, loss-corrected, manifold-projected) of
+// every observation -- what a Schur complement needs next to H_img / H_pt -- from the Jacobians this pass has
+// in registers anyway (no second sweep).  When the caller's observations are image-major (the order
+// AddImageToProblem creates them in, optim/bundle_adjustment.cc:814-919) the 144-B blocks of consecutive
+// lanes are adjacent in memory.
+template <int MODEL, bool WANT_W>
+__global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__ Himg, double* __restrict__ gimg,
+                                                   double* __restrict__ W_o) {
   const int im = blockIdx.x;
   const bool cpose = d.image_const_pose && d.image_const_pose[im];
   double acc[27];
@@ -232,6 +239,22 @@ __global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__
         for (int c = a; c < 6; ++c) acc[idx++] += J[a] * J[c] + J[6 + a] * J[6 + c];
 #pragma unroll
       for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r0 + J[6 + a] * r1;
+      if (WANT_W) {
+        const bool cpt = d.point_const && d.point_const[pt];
+        double* w = W_o + 18 * (size_t)d.img_obs[e];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            w[3 * a + c] = cpt ? 0.0 : J[a] * (sr * JX[c]) + J[6 + a] * (sr * JX[3 + c]);
+      }
+    }
+  } else if (WANT_W) {
+    // constant pose: no pose block, the coupling is zero
+    for (uint32_t e = d.img_obs_start[im] + threadIdx.x; e < d.img_obs_start[im + 1]; e += 256) {
+      double* w = W_o + 18 * (size_t)d.img_obs[e];
+#pragma unroll
+      for (int k = 0; k < 18; ++k) w[k] = 0.0;
     }
   }
   // fixed-order reduction: wave butterfly, then the 4 waves through LDS
@@ -383,7 +406,7 @@ struct pcd_ba {
   DevBuf<double> cam_params, poses, points, obs_xy, lidar_abcd, lidar_w, sell_xy, img_xy;
   DevBuf<uint8_t> image_const_pose, image_const_tvec, point_const;
   bool has_cpose = false, has_ctvec = false, has_cpt = false;
-  DevBuf<uint32_t> slice_start, pt_lidar_start, pt_lidar_list, img_obs_start;
+  DevBuf<uint32_t> slice_start, pt_lidar_start, pt_lidar_list, img_obs_start, img_obs;
   DevBuf<double> cost_partial, cost;
   // host-API staging
   DevBuf<double> o_res, o_jq, o_jt, o_jx, o_jl, o_himg, o_gimg, o_hpt, o_gpt, o_w, o_jc;
@@ -398,7 +421,7 @@ struct pcd_ba {
     d.lidar_point = lidar_point.p; d.lidar_abcd = lidar_abcd.p; d.lidar_w = lidar_w.p;
     d.pt_order = pt_order.p; d.slice_start = slice_start.p; d.sell_img = sell_img.p; d.sell_xy = sell_xy.p;
     d.pt_lidar_start = pt_lidar_start.p; d.pt_lidar_list = pt_lidar_list.p;
-    d.img_obs_start = img_obs_start.p; d.img_pt = img_pt.p; d.img_xy = img_xy.p;
+    d.img_obs_start = img_obs_start.p; d.img_pt = img_pt.p; d.img_xy = img_xy.p; d.img_obs = img_obs.p;
     d.I = I; d.P = P; d.nslices = nslices; d.O = O; d.L = L; d.loss_type = loss_type; d.loss_scale = loss_scale;
     return d;
   }
@@ -537,6 +560,7 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
       img_xy[2 * e + 1] = d->obs_xy[2 * (size_t)o + 1];
     }
     UP(img_obs_start, st.data(), st.size());
+    UP(img_obs, li.data(), li.size());
     UP(img_pt, img_pt.data(), img_pt.size());
     UP(img_xy, img_xy.data(), img_xy.size());
   }
@@ -589,14 +613,23 @@ pcd_status pcd_ba_evaluate_device(pcd_ba* b, const pcd_ba_out* o, void* stream) 
     }
     if (o->cost) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, b->cost_partial.p, (int)blocks, o->cost);
   }
+  // W rides on the image pass when that runs anyway (normal-equation mode); otherwise the raw kernel fills it
+  const bool w_fused = o->W && (o->H_img || o->g_img) && b->O;
   if (o->H_img || o->g_img) {
-    ScopedKernelTimer t("ba_images", s);
-    PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_images<M>), dim3(b->I), dim3(256), 0, s, d, o->H_img, o->g_img));
+    ScopedKernelTimer t(w_fused ? "ba_images_w" : "ba_images", s);
+    if (w_fused) {
+      PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_images<M, true>), dim3(b->I), dim3(256), 0, s, d, o->H_img,
+                                                 o->g_img, o->W));
+    } else {
+      PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_images<M, false>), dim3(b->I), dim3(256), 0, s, d, o->H_img,
+                                                 o->g_img, (double*)nullptr));
+    }
   }
-  if ((o->residuals || o->jac_q || o->jac_t || o->jac_X || o->W) && b->O) {
+  double* const W_raw = w_fused ? nullptr : o->W;
+  if ((o->residuals || o->jac_q || o->jac_t || o->jac_X || W_raw) && b->O) {
     ScopedKernelTimer t("ba_raw", s);
     PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_raw<M>), dim3(div_up(b->O, 256)), dim3(256), 0, s, d, o->residuals,
-                                               o->jac_q, o->jac_t, o->jac_X, o->W));
+                                               o->jac_q, o->jac_t, o->jac_X, W_raw));
   }
   if (o->jac_cam && b->O) {
     ScopedKernelTimer t("ba_cam_jac", s);

@@ -118,12 +118,14 @@ OPENCV_PARAMS = [3039.0, 3039.0, 2016.0, 1512.0, -0.05, 0.01, 1e-4, 1e-4]
 
 
 def ba_scene(num_cams, num_points, seed=11, mean_extra=4.0, lidar_frac=0.9, const_pose_frac=0.0,
-             max_track=30, scene_box=BOX):
+             max_track=30, scene_box=BOX, order="point"):
     """Returns a dict of flat arrays for pcdhip.BA / oracle BA.
 
     Cameras sit on a path along x at y ~ 2 m, looking roughly along +z/-z; each point is observed by
     L cameras (L = clip(Geom(0.25)+2, 2, max_track)) chosen among those nearest in x; the observation is
-    the exact projection + U(-2,2) px; poses are then perturbed."""
+    the exact projection + U(-2,2) px; poses are then perturbed.
+    order = "point": observations grouped by track; "image": grouped by image (stable), the order in which
+    BundleAdjuster::AddImageToProblem creates the residual blocks (optim/bundle_adjustment.cc:814-919)."""
     rng = np.random.default_rng(seed)
     cams_x = np.linspace(5, scene_box[0] - 5, num_cams)
     poses_true = np.empty((num_cams, 7))
@@ -163,6 +165,9 @@ def ba_scene(num_cams, num_points, seed=11, mean_extra=4.0, lidar_frac=0.9, cons
     obs_image, obs_point, Pc = obs_image[ok], obs_point[ok], Pc[ok]
     x, y = _opencv_project(OPENCV_PARAMS, Pc[:, 0] / Pc[:, 2], Pc[:, 1] / Pc[:, 2])
     obs_xy = np.stack([x, y], axis=1) + rng.uniform(-2, 2, (len(x), 2))
+    if order == "image":
+        perm = np.argsort(obs_image, kind="stable")
+        obs_image, obs_point, obs_xy = obs_image[perm], obs_point[perm], obs_xy[perm]
     # perturb the poses (what BA starts from)
     poses = poses_true.copy()
     ang = rng.normal(0, np.deg2rad(0.5), (num_cams, 3))

@@ -353,6 +353,23 @@ void oracle_ba_evaluate_raw(const oracle_ba_problem* p, double* residuals, doubl
   }
 }
 
+// Residual-only evaluation: what each CostFunction::Evaluate(parameters, residuals, nullptr) returns when
+// Ceres evaluates a trial step -- the functors instantiated with plain doubles, no Jets.
+void oracle_ba_residuals(const oracle_ba_problem* p, double* residuals) {
+  for (int64_t o = 0; o < p->num_obs; ++o) {
+    const int im = p->obs_image[o], pt = p->obs_point[o], cm = p->image_camera[im];
+    const double* pose = p->poses + 7 * (size_t)im;
+    reprojection_functor<double>(p->cam_model[cm], pose, pose + 4, p->points + 3 * (size_t)pt,
+                                 p->cam_params + p->cam_param_off[cm], p->obs_xy[2 * o], p->obs_xy[2 * o + 1],
+                                 residuals + 2 * o);
+  }
+  for (int64_t l = 0; l < p->num_lidar; ++l) {
+    const double* X = p->points + 3 * (size_t)p->lidar_point[l];
+    const double* pl = p->lidar_abcd + 4 * l;
+    lidar_functor<double>(X, pl[0], pl[1], pl[2], pl[3], p->lidar_weight[l], residuals + 2 * p->num_obs + l);
+  }
+}
+
 // Post-BA filters' inputs.  Per observation:
 //   sq_err = CalculateSquaredReprojectionError (base/projection.cc:104-117): P = R(q/|q|) X + t
 //            (base/pose.cc QuaternionRotatePoint normalises first; |q| == 0 -> identity),

@@ -74,6 +74,8 @@ def lib():
     L.oracle_loss.argtypes = [C.c_int, C.c_double, C.c_double, f64p]
     L.oracle_ba_evaluate_raw.restype = None
     L.oracle_ba_evaluate_raw.argtypes = [C.POINTER(BAProblem)] + [C.c_void_p] * 6
+    L.oracle_ba_residuals.restype = None
+    L.oracle_ba_residuals.argtypes = [C.POINTER(BAProblem), C.c_void_p]
     L.oracle_ba_normal_equations.restype = C.c_double
     L.oracle_ba_normal_equations.argtypes = [C.POINTER(BAProblem)] + [C.c_void_p] * 5
     L.oracle_sift_match.restype = C.c_int
@@ -159,6 +161,26 @@ class KDTree:
         sq = np.empty(nq, np.float32)
         found = np.empty(nq, np.uint8)
         lib().oracle_kdtree_query(self._h, q, nq, idx, sq, found)
+        return idx, sq, found
+
+    def query_mt(self, q, nthreads):
+        """the same serial search, queries split over `nthreads` host threads (the tree is read-only; ctypes
+        releases the GIL).  bench.py's all-cores CPU baseline; the reference itself queries serially."""
+        from concurrent.futures import ThreadPoolExecutor
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        nq = q.shape[0]
+        idx = np.empty(nq, np.uint32)
+        sq = np.empty(nq, np.float32)
+        found = np.empty(nq, np.uint8)
+        cuts = np.linspace(0, nq, nthreads + 1).astype(np.int64)
+        L = lib()
+
+        def run(k):
+            lo, hi = int(cuts[k]), int(cuts[k + 1])
+            if hi > lo:
+                L.oracle_kdtree_query(self._h, q[lo:hi], hi - lo, idx[lo:hi], sq[lo:hi], found[lo:hi])
+        with ThreadPoolExecutor(nthreads) as ex:
+            list(ex.map(run, range(nthreads)))
         return idx, sq, found
 
     def __del__(self):
@@ -306,6 +328,59 @@ class BA:
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         lib().oracle_ba_evaluate_raw(C.byref(self._p), vp(res), vp(Jq), vp(Jt), vp(JX), vp(Jc), vp(JL))
         return res, Jq, Jt, JX, Jc, JL
+
+    def residuals(self):
+        """residual-only evaluation (plain-double functors): CostFunction::Evaluate(params, r, nullptr)"""
+        res = np.zeros(2 * len(self.obs_image) + len(self.lidar_point))
+        lib().oracle_ba_residuals(C.byref(self._p), res.ctypes.data_as(C.c_void_p))
+        return res
+
+    def _chunks(self, nthreads):
+        """sub-problems over contiguous ranges of the observation / lidar blocks (pointer offsets, no copies)"""
+        O, Lc = len(self.obs_image), len(self.lidar_point)
+        oc = np.linspace(0, O, nthreads + 1).astype(np.int64)
+        lc = np.linspace(0, Lc, nthreads + 1).astype(np.int64)
+        out = []
+        for k in range(nthreads):
+            sp = BAProblem()
+            C.pointer(sp)[0] = self._p
+            o0, o1, l0, l1 = int(oc[k]), int(oc[k + 1]), int(lc[k]), int(lc[k + 1])
+            base = lambda a, off: C.c_void_p(a.ctypes.data + off)
+            sp.num_obs = o1 - o0
+            sp.obs_image = base(self.obs_image, 4 * o0); sp.obs_point = base(self.obs_point, 4 * o0)
+            sp.obs_xy = base(self.obs_xy, 16 * o0)
+            sp.num_lidar = l1 - l0
+            sp.lidar_point = base(self.lidar_point, 4 * l0); sp.lidar_abcd = base(self.lidar_abcd, 32 * l0)
+            sp.lidar_weight = base(self.lidar_weight, 8 * l0)
+            out.append((sp, o0, o1, l0, l1))
+        return out
+
+    def evaluate_mt(self, nthreads, jacobians=True):
+        """Ceres-style threaded evaluation: residual blocks split over `nthreads` host threads, each evaluating
+        its blocks with Jets (jacobians=True) or plain doubles.  bench.py's all-cores CPU baseline; outputs are
+        per-thread scratch (Ceres writes into its own Jacobian storage) and are discarded."""
+        from concurrent.futures import ThreadPoolExecutor
+        S = self.stride
+        L = lib()
+        work = []
+        for sp, o0, o1, l0, l1 in self._chunks(nthreads):
+            n, m = o1 - o0, l1 - l0
+            bufs = [np.empty(2 * n + m)]
+            if jacobians:
+                bufs += [np.empty((n, 2, 4)), np.empty((n, 2, 3)), np.empty((n, 2, 3)), np.empty((n, 2, S)),
+                         np.empty((m, 3))]
+            work.append((sp, bufs))
+
+        def run(w):
+            sp, bufs = w
+            ptrs = [b.ctypes.data_as(C.c_void_p) for b in bufs]
+            if jacobians:
+                L.oracle_ba_evaluate_raw(C.byref(sp), *ptrs)
+            else:
+                L.oracle_ba_residuals(C.byref(sp), ptrs[0])
+            return float(bufs[0] @ bufs[0])
+        with ThreadPoolExecutor(nthreads) as ex:
+            return 0.5 * sum(ex.map(run, work))
 
     def observation_errors(self):
         O = len(self.obs_image)
