@@ -66,6 +66,33 @@ __device__ __forceinline__ void eval_block(const BaDev& d, int im, const double 
   reproj_eval(model, d.cam_params + d.cam_off[cm], q, t, X, ox, oy, b);
 }
 
+// Coalesced store of one row of N doubles per lane, rows of consecutive lanes adjacent in memory
+// (out[(row0 + lane) * N + k] = v[k] for lane < cnt): the rows are transposed through a per-wavefront LDS
+// scratch of 64 * N doubles and leave as 16-B-per-lane stores of consecutive addresses (1 KiB per instruction)
+// instead of N stores that each touch 64 different cache lines.  Every lane of the wavefront must call it.
+template <int N>
+__device__ __forceinline__ void wave_store_rows(double* __restrict__ out, uint64_t row0, int cnt, const double (&v)[N],
+                                                double* __restrict__ lds) {
+  static_assert(N % 2 == 0, "rows are moved in 16-byte units");
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < N; ++k) lds[lane * N + k] = v[k];
+  // one wavefront: LDS operations complete in order; the fences keep the compiler from moving the reads up
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const double2* src = reinterpret_cast<const double2*>(lds);
+  double2* dst = reinterpret_cast<double2*>(out + row0 * N);
+  const int units = cnt * (N / 2);
+#pragma unroll
+  for (int j = 0; j < N / 2; ++j) {
+    const int u = j * 64 + lane;
+    if (u < units) dst[u] = src[u];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();   // the scratch may be rewritten after this
+}
+
 // ------------------------------------------------------------- points ------
 // BLOCKS = false: residual-only pass (cost), what Ceres asks for when it evaluates a trial step
 template <int MODEL, bool BLOCKS>
@@ -204,62 +231,76 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
 template <int MODEL, bool WANT_W>
 __global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__ Himg, double* __restrict__ gimg,
                                                    double* __restrict__ W_o) {
+  __shared__ __attribute__((aligned(16))) double s_w[WANT_W ? 4 : 1][WANT_W ? 64 * 18 : 2];
   const int im = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool cpose = d.image_const_pose && d.image_const_pose[im];
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-  if (!cpose) {
-    const unsigned tmask = d.image_const_tvec ? d.image_const_tvec[im] : 0u;
-    for (uint32_t e = d.img_obs_start[im] + threadIdx.x; e < d.img_obs_start[im + 1]; e += 256) {
-      const int pt = d.img_pt[e];
-      const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
-      ReprojBlock b;
-      double q[4];
-      eval_block<MODEL>(d, im, X, d.img_xy[2 * (size_t)e], d.img_xy[2 * (size_t)e + 1], b, q);
-      double rho0, rho1;
-      loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
-      const double sr = sqrt(rho1);
-      double Jq[8], Jt[6], JX[6], Jqt[6];
-      reproj_jacobians(b, Jq, Jt, JX);
-      quat_tangent(q, Jq, Jqt);
-      double J[12];  // 2 x 6
+  const unsigned tmask = d.image_const_tvec ? d.image_const_tvec[im] : 0u;
+  const uint32_t e_beg = d.img_obs_start[im], e_end = d.img_obs_start[im + 1];
+  if (!cpose || WANT_W) {
+    // every lane runs every iteration (the W store below is a whole-wavefront operation)
+    for (uint32_t e0 = e_beg; e0 < e_end; e0 += 256) {
+      const uint32_t e = e0 + threadIdx.x;
+      const bool active = e < e_end;
+      double w[18];
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+      for (int k = 0; k < 18; ++k) w[k] = 0.0;   // constant pose / constant point: the coupling is zero
+      if (active && !cpose) {
+        const int pt = d.img_pt[e];
+        const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
+        ReprojBlock b;
+        double q[4];
+        eval_block<MODEL>(d, im, X, d.img_xy[2 * (size_t)e], d.img_xy[2 * (size_t)e + 1], b, q);
+        double rho0, rho1;
+        loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
+        const double sr = sqrt(rho1);
+        double Jq[8], Jt[6], JX[6], Jqt[6];
+        reproj_jacobians(b, Jq, Jt, JX);
+        quat_tangent(q, Jq, Jqt);
+        double J[12];  // 2 x 6
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          J[6 * r + k] = sr * Jqt[3 * r + k];
-          J[6 * r + 3 + k] = ((tmask >> k) & 1u) ? 0.0 : sr * Jt[3 * r + k];
-        }
-      const double r0 = sr * b.r[0], r1 = sr * b.r[1];
-      int idx = 0;
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int c = a; c < 6; ++c) acc[idx++] += J[a] * J[c] + J[6 + a] * J[6 + c];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r0 + J[6 + a] * r1;
-      if (WANT_W) {
-        const bool cpt = d.point_const && d.point_const[pt];
-        double* w = W_o + 18 * (size_t)d.img_obs[e];
+          for (int k = 0; k < 3; ++k) {
+            J[6 * r + k] = sr * Jqt[3 * r + k];
+            J[6 * r + 3 + k] = ((tmask >> k) & 1u) ? 0.0 : sr * Jt[3 * r + k];
+          }
+        const double r0 = sr * b.r[0], r1 = sr * b.r[1];
+        int idx = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-          for (int c = 0; c < 3; ++c)
-            w[3 * a + c] = cpt ? 0.0 : J[a] * (sr * JX[c]) + J[6 + a] * (sr * JX[3 + c]);
-      }
-    }
-  } else if (WANT_W) {
-    // constant pose: no pose block, the coupling is zero
-    for (uint32_t e = d.img_obs_start[im] + threadIdx.x; e < d.img_obs_start[im + 1]; e += 256) {
-      double* w = W_o + 18 * (size_t)d.img_obs[e];
+          for (int c = a; c < 6; ++c) acc[idx++] += J[a] * J[c] + J[6 + a] * J[6 + c];
 #pragma unroll
-      for (int k = 0; k < 18; ++k) w[k] = 0.0;
+        for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r0 + J[6 + a] * r1;
+        if (WANT_W && !(d.point_const && d.point_const[pt])) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w[3 * a + c] = J[a] * (sr * JX[c]) + J[6 + a] * (sr * JX[3 + c]);
+        }
+      }
+      if (WANT_W) {
+        // rows of this wavefront: observation indices in the caller's order
+        const uint32_t o = active ? d.img_obs[e] : 0u;
+        const uint32_t o_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
+        const int cnt = (int)min(64u, e_end > e0 + wave * 64u ? e_end - (e0 + wave * 64u) : 0u);
+        const bool contiguous = __all(!active || o == o_first + (uint32_t)lane);
+        if (contiguous) {
+          wave_store_rows<18>(W_o, o_first, cnt, w, s_w[wave]);
+        } else if (active) {
+          double* dst = W_o + 18 * (size_t)o;
+#pragma unroll
+          for (int k = 0; k < 18; ++k) dst[k] = w[k];
+        }
+      }
     }
   }
   // fixed-order reduction: wave butterfly, then the 4 waves through LDS
   __shared__ double s_a[4][27];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     double v = acc[k];
@@ -287,37 +328,64 @@ template <int MODEL>
 __global__ __launch_bounds__(256) void k_ba_raw(BaDev d, double* __restrict__ residuals, double* __restrict__ Jq_o,
                                                 double* __restrict__ Jt_o, double* __restrict__ JX_o,
                                                 double* __restrict__ W_o) {
+  // thread = observation in the caller's order: the blocks of a wavefront are adjacent in every output array,
+  // so each array is written through wave_store_rows (coalesced 16-B stores)
+  __shared__ __attribute__((aligned(16))) double s_rows[4][64 * 18];
+  const int wave = threadIdx.x >> 6;
   const uint64_t o = blockIdx.x * (uint64_t)256 + threadIdx.x;
-  if (o >= d.O) return;
-  const int im = d.obs_image[o], pt = d.obs_point[o];
-  const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
-  ReprojBlock b;
-  double q[4];
-  eval_block<MODEL>(d, im, X, d.obs_xy[2 * o], d.obs_xy[2 * o + 1], b, q);
-  double Jq[8], Jt[6], JX[6];
-  reproj_jacobians(b, Jq, Jt, JX);
-  const bool cpose = d.image_const_pose && d.image_const_pose[im];
-  if (residuals) { residuals[2 * o] = b.r[0]; residuals[2 * o + 1] = b.r[1]; }
-  if (Jq_o) for (int k = 0; k < 8; ++k) Jq_o[8 * o + k] = cpose ? 0.0 : Jq[k];
-  if (Jt_o) for (int k = 0; k < 6; ++k) Jt_o[6 * o + k] = cpose ? 0.0 : Jt[k];
-  if (JX_o) for (int k = 0; k < 6; ++k) JX_o[6 * o + k] = JX[k];
-  if (W_o) {
-    double rho0, rho1;
-    loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
-    const double sr = sqrt(rho1);
-    const unsigned tmask = d.image_const_tvec ? d.image_const_tvec[im] : 0u;
-    const bool cpt = d.point_const && d.point_const[pt];
-    double Jqt[6], J[12], Jx[6];
-    quat_tangent(q, Jq, Jqt);
-    for (int r = 0; r < 2; ++r)
-      for (int k = 0; k < 3; ++k) {
-        J[6 * r + k] = cpose ? 0.0 : sr * Jqt[3 * r + k];
-        J[6 * r + 3 + k] = (cpose || ((tmask >> k) & 1u)) ? 0.0 : sr * Jt[3 * r + k];
-        Jx[3 * r + k] = cpt ? 0.0 : sr * JX[3 * r + k];
-      }
-    for (int a = 0; a < 6; ++a)
-      for (int c = 0; c < 3; ++c) W_o[18 * o + 3 * a + c] = J[a] * Jx[c] + J[6 + a] * Jx[3 + c];
+  const uint64_t o_wave = blockIdx.x * (uint64_t)256 + wave * 64;
+  if (o_wave >= d.O) return;   // whole wavefront past the end
+  const int cnt = (int)min((uint64_t)64, d.O - o_wave);
+  const bool active = o < d.O;
+  double res[2] = {0, 0}, Jq[8], Jt[6], JX[6], Wb[18];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) Jq[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { Jt[k] = 0.0; JX[k] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < 18; ++k) Wb[k] = 0.0;
+  if (active) {
+    const int im = d.obs_image[o], pt = d.obs_point[o];
+    const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
+    ReprojBlock b;
+    double q[4];
+    eval_block<MODEL>(d, im, X, d.obs_xy[2 * o], d.obs_xy[2 * o + 1], b, q);
+    reproj_jacobians(b, Jq, Jt, JX);
+    const bool cpose = d.image_const_pose && d.image_const_pose[im];
+    res[0] = b.r[0]; res[1] = b.r[1];
+    if (W_o) {
+      double rho0, rho1;
+      loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
+      const double sr = sqrt(rho1);
+      const unsigned tmask = d.image_const_tvec ? d.image_const_tvec[im] : 0u;
+      const bool cpt = d.point_const && d.point_const[pt];
+      double Jqt[6], J[12], Jx[6];
+      quat_tangent(q, Jq, Jqt);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          J[6 * r + k] = cpose ? 0.0 : sr * Jqt[3 * r + k];
+          J[6 * r + 3 + k] = (cpose || ((tmask >> k) & 1u)) ? 0.0 : sr * Jt[3 * r + k];
+          Jx[3 * r + k] = cpt ? 0.0 : sr * JX[3 * r + k];
+        }
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Wb[3 * a + c] = J[a] * Jx[c] + J[6 + a] * Jx[3 + c];
+    }
+    if (cpose) {   // the constant-pose functor has no pose blocks: zero rows
+#pragma unroll
+      for (int k = 0; k < 8; ++k) Jq[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Jt[k] = 0.0;
+    }
   }
+  if (residuals) wave_store_rows<2>(residuals, o_wave, cnt, res, s_rows[wave]);
+  if (Jq_o) wave_store_rows<8>(Jq_o, o_wave, cnt, Jq, s_rows[wave]);
+  if (Jt_o) wave_store_rows<6>(Jt_o, o_wave, cnt, Jt, s_rows[wave]);
+  if (JX_o) wave_store_rows<6>(JX_o, o_wave, cnt, JX, s_rows[wave]);
+  if (W_o) wave_store_rows<18>(W_o, o_wave, cnt, Wb, s_rows[wave]);
 }
 
 // Camera-parameter block of every reprojection residual (2 x K, row stride PCD_CAM_JAC_STRIDE).

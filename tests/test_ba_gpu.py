@@ -83,6 +83,16 @@ def test_normal_equations_and_cost(gpu, oracle, loss):
     _close(got["H_pt"], Hpt, 1e-9, "H_pt")
     _close(got["g_pt"], gpt, 1e-9, "g_pt")
     _close(got["W"], W, 1e-9, "W")
+    # W alone comes from the raw kernel instead of riding on the image pass: same blocks
+    _close(ba.evaluate(("W",))["W"], got["W"], 1e-13, "W raw vs fused")
+    # observations in image-major order (AddImageToProblem's): the fused pass writes W[o] through its e -> o map
+    perm = np.argsort(s["obs_image"], kind="stable")
+    s_img = dict(s); s_img["obs_image"], s_img["obs_point"], s_img["obs_xy"] = s["obs_image"][perm], s["obs_point"][perm], s["obs_xy"][perm]
+    ba_i = gpu.BA(**s_img, **kw)
+    got_i = ba_i.evaluate(("cost", "H_img", "W"))
+    _close(got_i["W"], W[perm], 1e-9, "W image-major")
+    _close(got_i["H_img"], Himg, 1e-9, "H_img image-major")
+    ba_i.close()
     # constant poses / points contribute no blocks
     cp = s["image_const_pose"].astype(bool)
     assert cp.any() and not got["H_img"][cp].any() and not got["H_pt"][pc.astype(bool)].any()
