@@ -36,9 +36,11 @@ static_assert(kTile == 256, "a tile is 4 DMA instructions (128/192-point tiles w
 // timing-only ablations (results are then wrong): compiled in only with -DPCD_ABLATE (tools/nn_ablate.py builds
 // such a variant); in the shipped library the masks are 0 and every `flags & kAblate*` folds away.
 #ifdef PCD_ABLATE
-constexpr int kAblateCompare = 0x100, kAblateReduce = 0x400, kAblateFallback = 0x800, kAblateTiles = 0x1000;
+constexpr int kAblateCompare = 0x100, kAblateReduce = 0x400, kAblateFallback = 0x800, kAblateTiles = 0x1000,
+              kAblateQuarter = 0x2000, kAblateNoDma = 0x4000, kAblateNoLdsRead = 0x8000;
 #else
-constexpr int kAblateCompare = 0, kAblateReduce = 0, kAblateFallback = 0, kAblateTiles = 0;
+constexpr int kAblateCompare = 0, kAblateReduce = 0, kAblateFallback = 0, kAblateTiles = 0, kAblateQuarter = 0,
+              kAblateNoDma = 0, kAblateNoLdsRead = 0;
 #endif
 
 __device__ __forceinline__ void lds_dma16(const float4* gsrc, float4* lds_wave_base) {
@@ -90,20 +92,64 @@ __device__ __forceinline__ uint64_t wave_min8_u64(const uint64_t (&v)[8]) {
   return c;
 }
 
-// One staged point against NQ wave-uniform queries: 8 scalar f32 ops (FLANN's ((dx*dx) + dy*dy) + dz*dz,
-// no FMA) + one u64 min of the packed (distance, index) key per query.  The kernel is bound by VALU
-// issue; measured alternatives that did NOT help: packed v_pk_add/mul_f32 for two queries per instruction
-// (1.13 ms vs 1.06 ms: the packed forms issue at half rate), 32-bit lexicographic compares instead of
-// v_cmp_lt_u64 (3 compares + 2 SALU per query), more wavefronts per SIMD (5, 6, 8: within 3 %).
+// One staged point against NQ wave-uniform queries: 8 scalar f32 ops (FLANN's ((dx*dx) + dy*dy) + dz*dz, no FMA)
+// + ONE v_min_f64 on the packed (distance, index) key per query.  The key float_bits(d) << 32 | index of a
+// non-negative, non-NaN float d is a positive finite (or denormal: d == 0) double whose numeric order is the
+// unsigned order of its bits, so the f64 minimum is exactly the lexicographic (distance, index) minimum that
+// v_cmp_lt_u64 + 2 v_cndmask computed before -- in one half-rate instruction instead of three (measured on
+// gfx950, tools/ubench/valu_rate.hip: v_cmp_lt_u64 4.2, v_min_f64 4.2, v_mul/v_fma_f32 2.4 cycles per wave64
+// instruction).  Inline asm: llvm's fmin would canonicalise both operands first (IEEE mode), two more f64 ops.
+// f64 denormals are never flushed on gfx9 compute kernels (only the f32 mode is configurable).
+// Measured alternatives that did NOT help: packed v_pk_add/mul_f32 (half rate on gfx950), 32-bit lexicographic
+// compares instead of the 64-bit one, more wavefronts per SIMD (5, 6, 8: within 3 %).
+// Hand-scheduled form.  hipcc builds each 64-bit key with an extra v_mov (the index into the low half of a fresh
+// register pair) and folds the wave-uniform queries into the subtractions as SGPR operands, which run at HALF rate
+// on gfx950 (tools/ubench/valu_rate2.hip: v_sub_f32 v,v 1.03 ns, s,v 1.75 ns per wave64 instruction); so the
+// queries are copied to VGPRs once per item and one staged point is compared with 4 queries per asm block:
+// per (point, query) pair 3 v_sub + 3 v_mul + 2 v_add + 1 v_min_f64 = 9 VALU instructions, plus one v_mov per
+// block that parks the point's index in the low half of the key pair v[120:121]; the last v_add writes the
+// distance straight into its high half.  Two queries are interleaved so that no instruction waits for its
+// predecessor.  Same IEEE operations in the same order as l2_simple3 (grid.h): results are bit-identical.
+// v118..v127 are scratch of the block (clobbers): the kernel stays within 128 VGPRs = 4 wavefronts per SIMD.
+#define PCD_CMP_PAIR(A, B)                                                                         \
+  "v_sub_f32 v122, %[qx" #A "], %[px]\n\tv_sub_f32 v125, %[qx" #B "], %[px]\n\t"                       \
+  "v_sub_f32 v123, %[qy" #A "], %[py]\n\tv_sub_f32 v126, %[qy" #B "], %[py]\n\t"                       \
+  "v_sub_f32 v124, %[qz" #A "], %[pz]\n\tv_sub_f32 v127, %[qz" #B "], %[pz]\n\t"                       \
+  "v_mul_f32 v122, v122, v122\n\tv_mul_f32 v125, v125, v125\n\t"                                     \
+  "v_mul_f32 v123, v123, v123\n\tv_mul_f32 v126, v126, v126\n\t"                                     \
+  "v_mul_f32 v124, v124, v124\n\tv_mul_f32 v127, v127, v127\n\t"                                     \
+  "v_add_f32 v122, v122, v123\n\tv_add_f32 v125, v125, v126\n\t"                                     \
+  "v_add_f32 v121, v122, v124\n\tv_add_f32 v119, v125, v127\n\t"                                     \
+  "v_min_f64 %[b" #A "], %[b" #A "], v[120:121]\n\tv_min_f64 %[b" #B "], %[b" #B "], v[118:119]\n\t"
+
+// one staged point against queries Q0..Q0+3 (whose coordinates are in VGPRs)
+__device__ __forceinline__ void compare_point4(const f32x4 p, const float* qx, const float* qy, const float* qz,
+                                               double* best) {
+  asm("v_mov_b32 v120, %[pw]\n\tv_mov_b32 v118, %[pw]\n\t"
+      PCD_CMP_PAIR(0, 1) PCD_CMP_PAIR(2, 3)
+      : [b0] "+v"(best[0]), [b1] "+v"(best[1]), [b2] "+v"(best[2]), [b3] "+v"(best[3])
+      : [px] "v"(p.x), [py] "v"(p.y), [pz] "v"(p.z), [pw] "v"(p.w),
+        [qx0] "v"(qx[0]), [qy0] "v"(qy[0]), [qz0] "v"(qz[0]), [qx1] "v"(qx[1]), [qy1] "v"(qy[1]), [qz1] "v"(qz[1]),
+        [qx2] "v"(qx[2]), [qy2] "v"(qy[2]), [qz2] "v"(qz[2]), [qx3] "v"(qx[3]), [qy3] "v"(qy[3]), [qz3] "v"(qz[3])
+      : "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+}
+__device__ __forceinline__ void compare_point2(const f32x4 p, const float* qx, const float* qy, const float* qz,
+                                               double* best) {
+  asm("v_mov_b32 v120, %[pw]\n\tv_mov_b32 v118, %[pw]\n\t"
+      PCD_CMP_PAIR(0, 1)
+      : [b0] "+v"(best[0]), [b1] "+v"(best[1])
+      : [px] "v"(p.x), [py] "v"(p.y), [pz] "v"(p.z), [pw] "v"(p.w),
+        [qx0] "v"(qx[0]), [qy0] "v"(qy[0]), [qz0] "v"(qz[0]), [qx1] "v"(qx[1]), [qy1] "v"(qy[1]), [qz1] "v"(qz[1])
+      : "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+}
+
 template <int NQ>
 __device__ __forceinline__ void compare_point(const f32x4 p, const float (&qx)[8], const float (&qy)[8],
-                                              const float (&qz)[8], uint64_t (&best)[8]) {
-  const uint32_t pi = __float_as_uint(p.w);
-#pragma unroll
-  for (int s = 0; s < NQ; ++s) {
-    const float d = l2_simple3(qx[s], qy[s], qz[s], p.x, p.y, p.z);
-    best[s] = min_u64(best[s], make_key(d, pi));
-  }
+                                              const float (&qz)[8], double (&best)[8]) {
+  static_assert(NQ == 2 || NQ == 4 || NQ == 8, "query slots come in pairs");
+  if (NQ == 2) compare_point2(p, qx, qy, qz, best);
+  if (NQ >= 4) compare_point4(p, qx, qy, qz, best);
+  if (NQ == 8) compare_point4(p, qx + 4, qy + 4, qz + 4, best + 4);
 }
 
 struct BrickMeta {   // per-group loads issued one group ahead
@@ -194,13 +240,13 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
 
     // ---- current group ----
     const uint32_t cnt = (uint32_t)item_count(it0);
-    float qx[G], qy[G], qz[G];   // wave-uniform (SGPRs)
+    float qx[G], qy[G], qz[G];   // wave-uniform, but held in VGPRs: SGPR operands halve the VALU rate (compare_point)
 #pragma unroll
     for (int k = 0; k < G; ++k) {
       const int src = k < (int)cnt ? k : 0;  // empty slots repeat query 0; their results are not written
-      qx[k] = readlane_f(m0.q.x, src);
-      qy[k] = readlane_f(m0.q.y, src);
-      qz[k] = readlane_f(m0.q.z, src);
+      asm volatile("v_mov_b32 %0, %1" : "=v"(qx[k]) : "s"(readlane_f(m0.q.x, src)));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(qy[k]) : "s"(readlane_f(m0.q.y, src)));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(qz[k]) : "s"(readlane_f(m0.q.z, src)));
     }
     int c0[3], c1[3];
     brick_region(g, b, it0, c0, c1);
@@ -210,9 +256,9 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
     const uint32_t off = wave_excl_scan_u32(len, T);
     const uint32_t delta = m0.s - off;
 
-    uint64_t best[G];
+    double best[G];   // packed keys, minimised as doubles (compare_point)
 #pragma unroll
-    for (int k = 0; k < G; ++k) best[k] = kKeyInit;
+    for (int k = 0; k < G; ++k) best[k] = __builtin_bit_cast(double, kKeyInit);
 
     if (T > 0 && !(flags & kAblateTiles)) {
       const int ntiles = (int)((T + kTile - 1) / kTile);
@@ -273,7 +319,8 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
           }
           // uniform base + byte offset (64-bit: a cloud may exceed 2^28 points = 4 GiB of records)
           const float4* gp = reinterpret_cast<const float4*>(src_bytes + ((uint64_t)idx << 4));
-          lds_dma16(gp, buf + k * 64);
+          if (!(flags & kAblateNoDma)) lds_dma16(gp, buf + k * 64);
+          else asm volatile("" ::"v"(gp));
         }
       };
       auto run_tiles = [&](auto fast_tag) {
@@ -291,6 +338,10 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
           // s_waitcnt vmcnt(0) (it cannot tell the two buffers apart) and drain tile t+1's DMAs.
           f32x4 p[4];
           const uint32_t rd = lds_addr(s_tile[wave][t & 1]) + lane * 16;
+          if (flags & kAblateNoLdsRead) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k] = f32x4{(float)lane, (float)t, (float)k, 0.f};
+          } else
           asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
                        "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
                        "s_waitcnt lgkmcnt(0)"
@@ -301,6 +352,10 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
           if (flags & kAblateCompare) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(p[k]));
+          } else if (flags & kAblateQuarter) {   // a quarter of the compare work, everything else unchanged
+            compare_point<G>(p[0], qx, qy, qz, best);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) asm volatile("" ::"v"(p[k]));
           } else if (cnt <= G / 4) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) compare_point<G / 4>(p[k], qx, qy, qz, best);
@@ -318,13 +373,18 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
       else run_tiles(std::false_type{});
     }
     // ---- one transposed reduction for the 8 queries; lane k fetches result k ----
-    const uint64_t red = (flags & kAblateReduce) ? best[0] : wave_min8_u64(best);
+    uint64_t best_u[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) best_u[k] = __builtin_bit_cast(uint64_t, best[k]);
+    const uint64_t red = (flags & kAblateReduce) ? best_u[0] : wave_min8_u64(best_u);
     // value index v sits in lanes with bits (5,4,3) = v  ->  lane 8*bitrev... v = b5*4 + b4*2 + b3
     const int holder = ((lane & 4) ? 32 : 0) | ((lane & 2) ? 16 : 0) | ((lane & 1) ? 8 : 0);
-    const uint64_t mine = ((uint64_t)__shfl((uint32_t)(red >> 32), holder) << 32) | __shfl((uint32_t)red, holder);
+    uint64_t mine = ((uint64_t)__shfl((uint32_t)(red >> 32), holder) << 32) | __shfl((uint32_t)red, holder);
     bool unproven = false;
     if (lane < (int)cnt) {
       const uint32_t my_qi = __float_as_uint(m0.q.w);
+      // the key the query came with: kKeyInit for a plain query, another shard's result for pcd_nn_refine_device
+      mine = min_u64(mine, keys[my_qi]);
       const double bound = proven_bound(g, m0.q.x, m0.q.y, m0.q.z, c0, c1);
       const double bd = (double)__uint_as_float((uint32_t)(mine >> 32));
       unproven = !(bd < bound) && !(flags & kAblateFallback);

@@ -53,6 +53,10 @@ void free_query_scratch(QueryScratch* s) { delete s; }
 
 constexpr uint64_t kKeyInit = (uint64_t)0x7F7FFFFFu << 32;  // (FLT_MAX, idx 0): nothing with d >= FLT_MAX beats it
 constexpr int kMaxRows = 64;                                // rows of a brick region (one per lane)
+// Batches up to this size skip the grid path (query sort + brick kernel + fallback = 13 launches) and go
+// straight to the per-wavefront hierarchical search, one launch: measured on a 2 M-point cloud
+// (tools/nn_latency.py), 20 k queries take 99 us that way against 190 us, 100 k queries 290 against 329.
+constexpr uint64_t kSmallBatch = 65536;
 
 // ------------------------------------------------------------ brick math ---
 struct BrickParams {
@@ -134,67 +138,67 @@ __global__ __launch_bounds__(256) void k_nn_bruteforce(const float4* __restrict_
 }
 
 // ------------------------------------------------------ brick bookkeeping ---
-__global__ void k_brick_count(const float4* __restrict__ qf4, uint64_t Q, GridParams g, BrickParams b,
-                              uint32_t* __restrict__ brick_of, uint32_t* __restrict__ rank,
-                              unsigned long long* __restrict__ brick_cnt, uint32_t* __restrict__ fb_list,
-                              NnCounters* __restrict__ ctr) {
+// O(Q), independent of the number of bricks: queries are sorted by brick id (rocPRIM radix sort of (brick, query)
+// pairs over the bits the brick count needs), runs of equal bricks are cut into work items of <= G queries with
+// two scans over the sorted keys, and one kernel writes the item records and the brick-sorted query records.
+// Keys: brick id | nbricks = finite query outside the grid (-> exact fallback) | nbricks + 1 = not finite (skipped).
+__global__ void k_brick_keys(const float4* __restrict__ qf4, uint64_t Q, GridParams g, BrickParams b,
+                             uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= Q) return;
-  float4 q = qf4[i];
-  uint32_t bid = 0xFFFFFFFFu;
+  const float4 q = qf4[i];
+  uint32_t bid = b.nbricks + 1u;
   if (q.w != 0.f) {
-    int cx = cell_coord_raw(q.x, g.origin[0], g.inv_h, g.dims[0]);
-    int cy = cell_coord_raw(q.y, g.origin[1], g.inv_h, g.dims[1]);
-    int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
-    bool in = cx >= 0 && cx < g.dims[0] && cy >= 0 && cy < g.dims[1] && cz >= 0 && cz < g.dims[2];
-    if (in) {
-      bid = (uint32_t)(((uint64_t)(cz / b.B) * b.nb[1] + (cy / b.B)) * b.nb[0] + (cx / b.B));
-      rank[i] = (uint32_t)atomicAdd(&brick_cnt[bid], 1ull);
-    } else {
-      // outside the grid: straight to the exact fallback
-      uint32_t pos = atomicAdd(&ctr->fb_count, 1u);
-      fb_list[pos] = (uint32_t)i;
-    }
+    const int cx = cell_coord_raw(q.x, g.origin[0], g.inv_h, g.dims[0]);
+    const int cy = cell_coord_raw(q.y, g.origin[1], g.inv_h, g.dims[1]);
+    const int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
+    const bool in = cx >= 0 && cx < g.dims[0] && cy >= 0 && cy < g.dims[1] && cz >= 0 && cz < g.dims[2];
+    bid = in ? (uint32_t)(((uint64_t)(cz / b.B) * b.nb[1] + (cy / b.B)) * b.nb[0] + (cx / b.B)) : b.nbricks;
   }
-  brick_of[i] = bid;
+  keys[i] = bid;
+  vals[i] = (uint32_t)i;
 }
 
-// per brick: lo32 = query count -> add item count in hi32
+// scan inputs computed on the fly from the sorted keys
+struct RunHeadPos {   // j -> j if a run of equal keys starts at j, else 0  (inclusive max-scan = start of j's run)
+  const uint32_t* keys;
+  __device__ uint32_t operator()(uint32_t j) const { return (j > 0 && keys[j - 1] != keys[j]) ? j : 0u; }
+};
 template <int G>
-__global__ void k_brick_items_count(unsigned long long* __restrict__ brick_cnt, uint32_t nbricks) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nbricks) return;
-  unsigned long long c = brick_cnt[b] & 0xFFFFFFFFull;
-  brick_cnt[b] = c | (((c + G - 1) / G) << 32);
-}
+struct ItemFlag {     // j -> 1 if a work item starts at j
+  const uint32_t* keys;
+  const uint32_t* run_start;
+  uint32_t nbricks;
+  __device__ uint32_t operator()(uint32_t j) const {
+    return (keys[j] < nbricks && ((j - run_start[j]) % G) == 0u) ? 1u : 0u;
+  }
+};
 
 template <int G>
-__global__ void k_brick_emit(const unsigned long long* __restrict__ brick_cnt,
-                             const unsigned long long* __restrict__ brick_off, uint32_t nbricks, uint32_t nb0, uint32_t nb1,
-                             uint4* __restrict__ items, NnCounters* __restrict__ ctr) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nbricks) return;
-  const uint32_t cnt = (uint32_t)(brick_cnt[b] & 0xFFFFFFFFull);
-  const uint32_t qoff = (uint32_t)(brick_off[b] & 0xFFFFFFFFull), ioff = (uint32_t)(brick_off[b] >> 32);
-  const uint32_t nit = (cnt + G - 1) / G;
-  // item record {first query, brick x, brick y, brick z | count << 28}: the brick kernel needs no divisions
-  const uint32_t bx = b % nb0, by = (b / nb0) % nb1, bz = b / (nb0 * nb1);
-  for (uint32_t k = 0; k < nit; ++k)
-    items[ioff + k] = make_uint4(qoff + k * G, bx, by, bz | (min((uint32_t)G, cnt - k * G) << 28));
-  if (b == nbricks - 1) ctr->nitems = ioff + nit;
-}
-
-// brick-sorted query records {x, y, z, bits(query id)}: the brick kernel reads them with one load
-__global__ void k_brick_scatter(const float4* __restrict__ qf4, const uint32_t* __restrict__ brick_of,
-                                const uint32_t* __restrict__ rank, const unsigned long long* __restrict__ brick_off,
-                                uint64_t Q, float4* __restrict__ qsorted) {
-  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-  if (i >= Q) return;
-  uint32_t b = brick_of[i];
-  if (b == 0xFFFFFFFFu) return;
-  float4 q = qf4[i];
-  q.w = __uint_as_float((uint32_t)i);
-  qsorted[(uint32_t)(brick_off[b] & 0xFFFFFFFFull) + rank[i]] = q;
+__global__ void k_brick_emit(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                             const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ item_idx,
+                             const float4* __restrict__ qf4, uint32_t Q, uint32_t nbricks, uint32_t nb0, uint32_t nb1,
+                             uint4* __restrict__ items, float4* __restrict__ qsorted, uint32_t* __restrict__ fb_list,
+                             NnCounters* __restrict__ ctr) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Q) return;
+  const uint32_t key = keys[j], v = vals[j];
+  const bool is_item = key < nbricks && ((j - run_start[j]) % G) == 0u;
+  if (key < nbricks) {
+    float4 q = qf4[v];
+    q.w = __uint_as_float(v);          // brick-sorted query record {x, y, z, bits(query id)}
+    qsorted[j] = q;
+    if (is_item) {
+      uint32_t cnt = 1;
+      while (cnt < (uint32_t)G && j + cnt < Q && keys[j + cnt] == key) ++cnt;
+      // item record {first query, brick x, brick y, brick z | count << 28}: the brick kernel needs no divisions
+      const uint32_t bx = key % nb0, by = (key / nb0) % nb1, bz = key / (nb0 * nb1);
+      items[item_idx[j]] = make_uint4(j, bx, by, bz | (cnt << 28));
+    }
+  } else if (key == nbricks) {
+    fb_list[atomicAdd(&ctr->fb_count, 1u)] = v;   // outside the grid: straight to the exact fallback
+  }
+  if (j == Q - 1) ctr->nitems = item_idx[j] + (is_item ? 1u : 0u);
 }
 
 // ------------------------------------------------------------ brick kernel ---
@@ -380,32 +384,40 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   int B = g_brick_B, R = g_brick_R;
   if ((B + 2 * R) * (B + 2 * R) > kMaxRows) { B = 2; R = 2; }
   const BrickParams b = make_bricks(g, B, R);
-  PCD_TRY(sc->brick_of.reserve(Q));
-  PCD_TRY(sc->rank.reserve(Q));
   PCD_TRY(sc->qsorted.reserve(Q));
   PCD_TRY(sc->fb_list.reserve(Q));
-  PCD_TRY(sc->brick_cnt.reserve(b.nbricks));
-  PCD_TRY(sc->brick_off.reserve(b.nbricks));
-  PCD_TRY(sc->items.reserve(Q / G + std::min<uint64_t>(b.nbricks, Q) + 1));
+  PCD_TRY(sc->bk_keys.reserve(2 * Q));
+  PCD_TRY(sc->bk_vals.reserve(2 * Q));
+  PCD_TRY(sc->bk_run.reserve(Q));
+  PCD_TRY(sc->bk_item.reserve(Q));
+  PCD_TRY(sc->items.reserve(Q + 1));
   PCD_TRY(sc->counters.reserve(1));
   PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
-  PCD_HIP_TRY(hipMemsetAsync(sc->brick_cnt.p, 0, sizeof(unsigned long long) * b.nbricks, s));
   {
     ScopedKernelTimer t("nn_brick_bookkeeping", s);
-    hipLaunchKernelGGL(k_brick_count, dim3(div_up(Q, 256)), dim3(256), 0, s, sc->qf4.p, Q, g, b, sc->brick_of.p,
-                       sc->rank.p, sc->brick_cnt.p, sc->fb_list.p, sc->counters.p);
-    hipLaunchKernelGGL(k_brick_items_count<G>, dim3(div_up(b.nbricks, 256)), dim3(256), 0, s, sc->brick_cnt.p,
-                       b.nbricks);
+    uint32_t *k0 = sc->bk_keys.p, *k1 = sc->bk_keys.p + Q, *v0 = sc->bk_vals.p, *v1 = sc->bk_vals.p + Q;
+    hipLaunchKernelGGL(k_brick_keys, dim3(div_up(Q, 256)), dim3(256), 0, s, sc->qf4.p, Q, g, b, k0, v0);
+    unsigned end_bit = 1;
+    while (end_bit < 32 && ((uint64_t)1 << end_bit) <= (uint64_t)b.nbricks + 1) ++end_bit;
     size_t tb = 0;
-    PCD_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, sc->brick_cnt.p, sc->brick_off.p, 0ull, b.nbricks,
-                                        rocprim::plus<unsigned long long>(), s));
+    // rocPRIM's default takes its merge sort (log2(Q / block) launches) up to 2^20 items: Onesweep above 32 k
+    using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                               rocprim::default_config, 32768>;
+    PCD_HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tb, k0, k1, v0, v1, (unsigned)Q, 0u, end_bit, s));
     PCD_TRY(sc->tmp.reserve(tb));
-    PCD_HIP_TRY(rocprim::exclusive_scan(sc->tmp.p, tb, sc->brick_cnt.p, sc->brick_off.p, 0ull, b.nbricks,
-                                        rocprim::plus<unsigned long long>(), s));
-    hipLaunchKernelGGL(k_brick_emit<G>, dim3(div_up(b.nbricks, 256)), dim3(256), 0, s, sc->brick_cnt.p,
-                       sc->brick_off.p, b.nbricks, (uint32_t)b.nb[0], (uint32_t)b.nb[1], sc->items.p, sc->counters.p);
-    hipLaunchKernelGGL(k_brick_scatter, dim3(div_up(Q, 256)), dim3(256), 0, s, sc->qf4.p, sc->brick_of.p, sc->rank.p,
-                       sc->brick_off.p, Q, sc->qsorted.p);
+    PCD_HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(sc->tmp.p, tb, k0, k1, v0, v1, (unsigned)Q, 0u, end_bit, s));
+    const auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), RunHeadPos{k1});
+    PCD_HIP_TRY(rocprim::inclusive_scan(nullptr, tb, heads, sc->bk_run.p, (size_t)Q, rocprim::maximum<uint32_t>(), s));
+    PCD_TRY(sc->tmp.reserve(tb));
+    PCD_HIP_TRY(rocprim::inclusive_scan(sc->tmp.p, tb, heads, sc->bk_run.p, (size_t)Q, rocprim::maximum<uint32_t>(), s));
+    const auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u),
+                                                        ItemFlag<G>{k1, sc->bk_run.p, b.nbricks});
+    PCD_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, flags, sc->bk_item.p, 0u, (size_t)Q, rocprim::plus<uint32_t>(), s));
+    PCD_TRY(sc->tmp.reserve(tb));
+    PCD_HIP_TRY(rocprim::exclusive_scan(sc->tmp.p, tb, flags, sc->bk_item.p, 0u, (size_t)Q, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(k_brick_emit<G>, dim3(div_up(Q, 256)), dim3(256), 0, s, k1, v1, sc->bk_run.p, sc->bk_item.p,
+                       sc->qf4.p, (uint32_t)Q, b.nbricks, (uint32_t)b.nb[0], (uint32_t)b.nb[1], sc->items.p,
+                       sc->qsorted.p, sc->fb_list.p, sc->counters.p);
   }
   {
     ScopedKernelTimer t("nn_brick", s);
@@ -444,7 +456,7 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
       chunks = div_up(c->n, chunk);
       hipLaunchKernelGGL(k_nn_bruteforce, dim3(qblocks, chunks), dim3(256), 0, s, c->pts4.p, c->n, c->index_base,
                          c->index_stride, sc->qf4.p, Q, chunk, d_keys);
-    } else if (algo == PCD_NN_FALLBACK_ONLY) {
+    } else if (algo == PCD_NN_FALLBACK_ONLY || (algo == PCD_NN_AUTO && Q <= kSmallBatch)) {
       PCD_TRY(sc->counters.reserve(1));
       PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
       ScopedKernelTimer t("nn_fallback", s);
@@ -452,7 +464,7 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
       hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, c->grid, c->pyr, c->sorted.p, c->cell_start.p,
                          c->blk_aabb.p, sc->qf4.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)Q,
                          d_keys, sc->counters.p, g_collect_stats);
-    } else if (algo == PCD_NN_AUTO) {
+    } else if (algo == PCD_NN_AUTO || algo == PCD_NN_GRID) {
       PCD_TRY(run_grid<8>(c, sc, Q, d_keys, s));
     } else {
       set_error("unknown nn algo %d", algo);

@@ -13,12 +13,10 @@ struct NnCounters {
 struct QueryScratch {
   DevBuf<float4> qf4;          // (float)query, w = 1 valid / 0 not finite
   DevBuf<uint64_t> keys;       // host-API result keys
-  DevBuf<uint32_t> brick_of;   // per query: brick id or 0xFFFFFFFF
-  DevBuf<uint32_t> rank;       // per query: rank inside its brick
+  DevBuf<uint32_t> bk_keys, bk_vals;   // (brick id, query id) pairs, unsorted | sorted halves
+  DevBuf<uint32_t> bk_run, bk_item;    // per sorted position: start of its run, index of the item starting there
   DevBuf<float4> qsorted;      // brick-sorted query records {x,y,z,bits(query id)}
-  DevBuf<unsigned long long> brick_cnt;  // per brick: lo32 = queries, hi32 = items (scan input)
-  DevBuf<unsigned long long> brick_off;  // exclusive scan of the above
-  DevBuf<uint4> items;         // {first, brick, count, 0}
+  DevBuf<uint4> items;         // {first query, brick x, brick y, brick z | count << 28}
   DevBuf<uint32_t> fb_list;
   DevBuf<NnCounters> counters;
   DevBuf<char> tmp;

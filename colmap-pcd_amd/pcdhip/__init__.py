@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_PKG)            # colmap-pcd_amd/
 LIB_PATH = os.environ.get("PCDHIP_LIB", os.path.join(_ROOT, "libpcdhip.so"))   # override: tuning variants only
 
 PCD_OK, PCD_ERR_INVALID, PCD_ERR_NO_DEVICE, PCD_ERR_HIP, PCD_ERR_OOM, PCD_ERR_UNSUPPORTED = range(6)
-NN_AUTO, NN_BRUTEFORCE, NN_FALLBACK_ONLY = 0, 1, 2
+NN_AUTO, NN_BRUTEFORCE, NN_FALLBACK_ONLY, NN_GRID = 0, 1, 2, 3
 GATE_MAPPER_LOCAL, GATE_MAPPER_GLOBAL, GATE_CONTROLLER = 0, 1, 2
 LIDAR_NONE, LIDAR_ICP, LIDAR_ICP_GROUND = 0, 1, 2
 LOSS_TRIVIAL, LOSS_SOFT_L1, LOSS_CAUCHY = 0, 1, 2

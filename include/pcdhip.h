@@ -103,9 +103,10 @@ pcd_status pcd_cloud_download(const pcd_cloud* c, float* xyz /*[size][3]*/, floa
  * closer than FLT_MAX; idx is then 0xFFFFFFFF and sqdist FLT_MAX.
  * --------------------------------------------------------------------- */
 typedef enum {
-  PCD_NN_AUTO = 0,        /* grid kernels (brick LDS tiles + exact fallback)  */
+  PCD_NN_AUTO = 0,        /* PCD_NN_GRID for large batches, PCD_NN_FALLBACK_ONLY for small ones (one launch) */
   PCD_NN_BRUTEFORCE = 1,  /* tiled all-pairs kernel: reference for the others */
-  PCD_NN_FALLBACK_ONLY = 2/* per-wavefront hierarchical search for every query */
+  PCD_NN_FALLBACK_ONLY = 2,/* per-wavefront hierarchical search for every query */
+  PCD_NN_GRID = 3         /* grid kernels (query sort + brick LDS tiles + exact fallback) whatever the batch size */
 } pcd_nn_algo;
 
 pcd_status pcd_nn_query(pcd_cloud* c, const double* q_xyz /*[Q][3]*/, uint64_t Q,

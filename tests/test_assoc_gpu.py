@@ -76,7 +76,7 @@ def test_sharded_cloud_min_and_payload(gpu, oracle):
     dq = torch.from_numpy(q).cuda()
     keys = [torch.empty(Q, dtype=torch.int64, device="cuda") for _ in range(S)]
     for s in range(S):
-        shards[s].nn_device(dq, Q, keys[s])
+        shards[s].nn_device(dq, Q, keys[s], gpu.NN_GRID)    # grid path (AUTO takes the one-launch path here)
     kmin = torch.stack(keys).min(dim=0).values
     payload = torch.zeros(Q, 6, dtype=torch.int32, device="cuda")
     for s in range(S):

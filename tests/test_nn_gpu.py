@@ -10,7 +10,7 @@ from pcdhip import synth
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = ["AUTO", "BRUTEFORCE", "FALLBACK_ONLY"]
+ALGOS = ["AUTO", "GRID", "BRUTEFORCE", "FALLBACK_ONLY"]   # AUTO = FALLBACK_ONLY at these batch sizes
 
 
 def _algo(pcdhip, name):
@@ -60,7 +60,7 @@ def test_nn_parity_any_cell_size(gpu, oracle, cell):
     q = synth.queries(xyz, 3000, seed=17, sigma=0.6)
     c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False, cell_size=cell)
     exp = oracle.nn_bruteforce(xyz, q)
-    for algo in ("AUTO", "FALLBACK_ONLY"):
+    for algo in ("GRID", "FALLBACK_ONLY"):
         _check_exact(c.nn(q, _algo(gpu, algo)), exp, f"cell={cell}/{algo}")
     c.close()
 
@@ -230,5 +230,6 @@ def test_far_from_origin(gpu, offset):
     xyz = (xyz.astype(np.float64) + offset).astype(np.float32)
     q = synth.queries(xyz, 30_000, seed=4)
     c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
-    _check_exact(c.nn(q), c.nn(q, gpu.NN_BRUTEFORCE), f"grid vs brute force at offset {offset}")
+    _check_exact(c.nn(q, gpu.NN_GRID), c.nn(q, gpu.NN_BRUTEFORCE), f"grid vs brute force at offset {offset}")
+    _check_exact(c.nn(q), c.nn(q, gpu.NN_BRUTEFORCE), f"auto vs brute force at offset {offset}")
     c.close()

@@ -17,7 +17,9 @@ c = pcdhip.Cloud(xyz, nrm, raw_lidar_frame=False)
 dq = torch.from_numpy(q).cuda()
 keys = torch.empty(Q, dtype=torch.int64, device="cuda")
 F = 0x800  # never hand anything to the fallback (keeps the brick kernel's control flow comparable)
-for name, fl in [("full", 0), ("full, no fallback list", F), ("no-compare", F | 0x100), ("no-reduce", F | 0x400),
+for name, fl in [("full", 0), ("full, no fallback list", F), ("no-compare", F | 0x100), ("quarter compare", F | 0x2000),
+                 ("no-reduce", F | 0x400), ("no DMA (stale LDS)", F | 0x4000), ("no DMA, no LDS read", F | 0xC000),
+                 ("no DMA, no LDS read, no compare", F | 0xC100), ("no LDS read", F | 0x8000),
                  ("no-compare+no-reduce", F | 0x500), ("no tile loop, no reduce", F | 0x1400), ("no tile loop", F | 0x1000),
                  ("full", 0)]:
     pcdhip.set_nn_tuning(0, -1, fl)
