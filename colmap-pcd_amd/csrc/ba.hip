@@ -47,6 +47,12 @@ struct BaDev {
   const uint32_t* img_obs_start;  // [I+1]
   const int* img_pt;              // [O] point of the e-th observation of the image-major order
   const uint32_t* img_obs;        // [O] its index in the caller's observation order (W is written there)
+  const uint8_t* cam_refine;      // [cam_params_len] 1 = parameter optimised (nullptr: all constant)
+  const uint32_t* cam_img_start;  // [C+1] images of each camera (CSR, ascending image index)
+  const uint32_t* cam_img_list;
+  int C;
+  int cam_k;                      // K of the camera accumulation: the model's when one of the compiled-in models is
+                                  // used by every camera, PCD_CAM_JAC_STRIDE for the generic (per-observation switch) path
   const double* img_xy;           // [O][2]
   int I, P, nslices; uint64_t O, L;
   int loss_type; double loss_scale;
@@ -323,6 +329,215 @@ __global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__
   }
 }
 
+// ------------------------------------------------------------ cameras ------
+// Camera blocks of the normal equations (refined intrinsics; ParameterizeCameras, optim/bundle_adjustment.cc:
+// 1047-1100).  Per image the accumulation has NE = K(K+1)/2 + 6K + K entries -- upper triangle of Jc^T Jc,
+// Jc^T Jp (K x 6), Jc^T r -- too many to keep per lane next to the Jacobians, so the four wavefronts of the
+// workgroup each own a quarter of the entries and every wavefront sweeps all observations of the image
+// (Jacobians recomputed four times; this pass only runs when intrinsics are refined, which the fork's defaults
+// switch off).  Entry -> operand columns is resolved at compile time (K and the chunk are template constants).
+// Fixed-order reductions, no atomics: bitwise reproducible.  k_ba_cameras_reduce then sums the images of a camera.
+__host__ __device__ constexpr int cam_ne(int K) { return K * (K + 1) / 2 + 6 * K + K; }
+// operand columns of entry e in A = [Jc (K) | Jp (6) | r (1)]
+__host__ __device__ constexpr int cam_ent_l(int K, int e) {
+  const int ncc = K * (K + 1) / 2;
+  if (e < ncc) { int a = 0; while (e >= K - a) { e -= K - a; ++a; } return a; }
+  e -= ncc;
+  if (e < 6 * K) return e / 6;
+  return e - 6 * K;
+}
+__host__ __device__ constexpr int cam_ent_r(int K, int e) {
+  const int ncc = K * (K + 1) / 2;
+  if (e < ncc) { int a = 0; while (e >= K - a) { e -= K - a; ++a; } return a + e; }
+  e -= ncc;
+  if (e < 6 * K) return K + e % 6;
+  return K + 6;
+}
+
+template <int MODEL, int CH>
+__device__ __forceinline__ void cam_accumulate(const BaDev& d, int im, double* __restrict__ partial) {
+  constexpr int K = MODEL >= 0 ? cam_num_params(MODEL >= 0 ? MODEL : 0) : PCD_CAM_JAC_STRIDE;
+  constexpr int NE = cam_ne(K), PER = (NE + 3) / 4, E0 = CH * PER, E1 = E0 + PER < NE ? E0 + PER : NE;
+  constexpr int NA = K + 7;
+  const int lane = threadIdx.x & 63;
+  const bool cpose = d.image_const_pose && d.image_const_pose[im];
+  const unsigned tmask = d.image_const_tvec ? d.image_const_tvec[im] : 0u;
+  const int cm = d.image_cam[im];
+  const double* cam = d.cam_params + d.cam_off[cm];
+  const uint8_t* refine = d.cam_refine ? d.cam_refine + d.cam_off[cm] : nullptr;
+  const int model = MODEL >= 0 ? MODEL : d.cam_model[cm];
+  double acc[PER > 0 ? PER : 1];
+#pragma unroll
+  for (int t = 0; t < PER; ++t) acc[t] = 0.0;
+  for (uint32_t e = d.img_obs_start[im] + lane; e < d.img_obs_start[im + 1]; e += 64) {
+    const int pt = d.img_pt[e];
+    const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
+    ReprojBlock b;
+    double q[4];
+    eval_block<MODEL>(d, im, X, d.img_xy[2 * (size_t)e], d.img_xy[2 * (size_t)e + 1], b, q);
+    double rho0, rho1;
+    loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
+    const double sr = sqrt(rho1);
+    double A[2][NA];
+    {  // camera columns: same normalised coordinates as reproj_eval
+      const double* pose = d.poses + 7 * (size_t)im;
+      const double w = pose[0], a = pose[1], bq = pose[2], c = pose[3];
+      const double cx = bq * X[2] - c * X[1], cy = c * X[0] - a * X[2], cz = a * X[1] - bq * X[0];
+      const double ux = 2.0 * cx, uy = 2.0 * cy, uz = 2.0 * cz;
+      const double Px = X[0] + w * ux + (bq * uz - c * uy) + pose[4];
+      const double Py = X[1] + w * uy + (c * ux - a * uz) + pose[5];
+      const double Pz = X[2] + w * uz + (a * uy - bq * ux) + pose[6];
+      const double iz = 1.0 / Pz;
+      double Jc[2 * K];
+#pragma unroll
+      for (int k = 0; k < 2 * K; ++k) Jc[k] = 0.0;
+      if (MODEL >= 0) cam_param_jacobian<(MODEL >= 0 ? MODEL : 0)>(cam, Px * iz, Py * iz, Jc, K);
+      else cam_param_jacobian_any(model, cam, Px * iz, Py * iz, Jc, K);
+      const int kn = MODEL >= 0 ? K : cam_num_params(model);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const bool var = refine && k < kn && refine[k < kn ? k : 0];
+        A[0][k] = var ? sr * Jc[k] : 0.0;
+        A[1][k] = var ? sr * Jc[K + k] : 0.0;
+      }
+    }
+    double Jq[8], Jt[6], JX[6], Jqt[6];
+    reproj_jacobians(b, Jq, Jt, JX);
+    quat_tangent(q, Jq, Jqt);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        A[r][K + k] = cpose ? 0.0 : sr * Jqt[3 * r + k];
+        A[r][K + 3 + k] = (cpose || ((tmask >> k) & 1u)) ? 0.0 : sr * Jt[3 * r + k];
+      }
+      A[r][K + 6] = sr * b.r[r];
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      if (E0 + t < E1) {
+        const int l = cam_ent_l(K, E0 + t), r = cam_ent_r(K, E0 + t);
+        acc[t] += A[0][l] * A[0][r] + A[1][l] * A[1][r];
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    if (E0 + t < E1) {
+      double v = acc[t];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) partial[(size_t)im * cam_ne(PCD_CAM_JAC_STRIDE) + E0 + t] = v;
+    }
+  }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_ba_cameras(BaDev d, double* __restrict__ partial) {
+  const int im = blockIdx.x;
+  switch (threadIdx.x >> 6) {
+    case 0: cam_accumulate<MODEL, 0>(d, im, partial); break;
+    case 1: cam_accumulate<MODEL, 1>(d, im, partial); break;
+    case 2: cam_accumulate<MODEL, 2>(d, im, partial); break;
+    default: cam_accumulate<MODEL, 3>(d, im, partial); break;
+  }
+}
+
+// partial [I][NE(12)] (entries laid out for the image's own K) -> H_cam / g_cam per camera (images summed in
+// ascending order) and E_cam per image
+__global__ __launch_bounds__(256) void k_ba_cameras_reduce(BaDev d, const double* __restrict__ partial,
+                                                           double* __restrict__ Hcam, double* __restrict__ gcam,
+                                                           double* __restrict__ Ecam) {
+  constexpr int S = PCD_CAM_JAC_STRIDE, NEMAX = cam_ne(S);
+  const int c = blockIdx.x;
+  const int model = d.cam_model[c];
+  const int K = d.cam_k;
+  (void)model;
+  const int ncc = K * (K + 1) / 2, NE = ncc + 7 * K;
+  for (int e = threadIdx.x; e < S * S + S; e += 256) {   // zero-fill, then the K x K / K part
+    if (e < S * S) { if (Hcam) Hcam[(size_t)c * S * S + e] = 0.0; }
+    else if (gcam) gcam[(size_t)c * S + (e - S * S)] = 0.0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NE; e += 256) {
+    if (e >= ncc && e < ncc + 6 * K) continue;   // coupling entries are per image
+    double v = 0.0;
+    for (uint32_t j = d.cam_img_start[c]; j < d.cam_img_start[c + 1]; ++j)
+      v += partial[(size_t)d.cam_img_list[j] * NEMAX + e];
+    if (e < ncc) {
+      int a = 0, k = e;
+      while (k >= K - a) { k -= K - a; ++a; }
+      const int b = a + k;
+      if (Hcam) { Hcam[(size_t)c * S * S + a * S + b] = v; Hcam[(size_t)c * S * S + b * S + a] = v; }
+    } else if (gcam) {
+      gcam[(size_t)c * S + (e - ncc - 6 * K)] = v;
+    }
+  }
+  if (Ecam) {
+    for (uint32_t j = d.cam_img_start[c]; j < d.cam_img_start[c + 1]; ++j) {
+      const uint32_t im = d.cam_img_list[j];
+      for (int e = threadIdx.x; e < S * 6; e += 256) {
+        const int a = e / 6;
+        Ecam[(size_t)im * S * 6 + e] = a < K ? partial[(size_t)im * NEMAX + ncc + e] : 0.0;
+      }
+    }
+  }
+}
+
+// camera x point coupling of every observation: W_cam[o] = Jc^T JX (S x 3, loss-corrected, masks applied)
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_ba_cam_w(BaDev d, double* __restrict__ Wc_o) {
+  constexpr int S = PCD_CAM_JAC_STRIDE;
+  __shared__ __attribute__((aligned(16))) double s_rows[4][64 * 3 * S];
+  const int wave = threadIdx.x >> 6;
+  const uint64_t o = blockIdx.x * (uint64_t)256 + threadIdx.x;
+  const uint64_t o_wave = blockIdx.x * (uint64_t)256 + wave * 64;
+  if (o_wave >= d.O) return;
+  const int cnt = (int)min((uint64_t)64, d.O - o_wave);
+  double Wc[3 * S];
+#pragma unroll
+  for (int k = 0; k < 3 * S; ++k) Wc[k] = 0.0;
+  if (o < d.O) {
+    const int im = d.obs_image[o], pt = d.obs_point[o];
+    const bool cpt = d.point_const && d.point_const[pt];
+    const int cm = d.image_cam[im];
+    const uint8_t* refine = d.cam_refine ? d.cam_refine + d.cam_off[cm] : nullptr;
+    if (!cpt && refine) {
+      const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
+      ReprojBlock b;
+      double q[4];
+      eval_block<MODEL>(d, im, X, d.obs_xy[2 * o], d.obs_xy[2 * o + 1], b, q);
+      double rho0, rho1;
+      loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
+      double Jq[8], Jt[6], JX[6];
+      reproj_jacobians(b, Jq, Jt, JX);
+      const double* pose = d.poses + 7 * (size_t)im;
+      const double w = pose[0], a = pose[1], bq = pose[2], c = pose[3];
+      const double cx = bq * X[2] - c * X[1], cy = c * X[0] - a * X[2], cz = a * X[1] - bq * X[0];
+      const double ux = 2.0 * cx, uy = 2.0 * cy, uz = 2.0 * cz;
+      const double Px = X[0] + w * ux + (bq * uz - c * uy) + pose[4];
+      const double Py = X[1] + w * uy + (c * ux - a * uz) + pose[5];
+      const double Pz = X[2] + w * uz + (a * uy - bq * ux) + pose[6];
+      const double iz = 1.0 / Pz;
+      const int model = MODEL >= 0 ? MODEL : d.cam_model[cm];
+      double Jc[2 * S];
+#pragma unroll
+      for (int k = 0; k < 2 * S; ++k) Jc[k] = 0.0;
+      if (MODEL >= 0) cam_param_jacobian<(MODEL >= 0 ? MODEL : 0)>(d.cam_params + d.cam_off[cm], Px * iz, Py * iz, Jc, S);
+      else cam_param_jacobian_any(model, d.cam_params + d.cam_off[cm], Px * iz, Py * iz, Jc, S);
+      const int kn = cam_num_params(model);
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        const bool var = k < kn && refine[k < kn ? k : 0];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          Wc[3 * k + j] = var ? rho1 * (Jc[k] * JX[j] + Jc[S + k] * JX[3 + j]) : 0.0;
+      }
+    }
+  }
+  wave_store_rows<3 * S>(Wc_o, o_wave, cnt, Wc, s_rows[wave]);
+}
+
 // ---------------------------------------------------------------- raw ------
 template <int MODEL>
 __global__ __launch_bounds__(256) void k_ba_raw(BaDev d, double* __restrict__ residuals, double* __restrict__ Jq_o,
@@ -474,10 +689,13 @@ struct pcd_ba {
   DevBuf<double> cam_params, poses, points, obs_xy, lidar_abcd, lidar_w, sell_xy, img_xy;
   DevBuf<uint8_t> image_const_pose, image_const_tvec, point_const;
   bool has_cpose = false, has_ctvec = false, has_cpt = false;
-  DevBuf<uint32_t> slice_start, pt_lidar_start, pt_lidar_list, img_obs_start, img_obs;
+  DevBuf<uint32_t> slice_start, pt_lidar_start, pt_lidar_list, img_obs_start, img_obs, cam_img_start, cam_img_list;
+  DevBuf<uint8_t> cam_refine;
+  bool has_refine = false;
+  DevBuf<double> cam_partial;
   DevBuf<double> cost_partial, cost;
   // host-API staging
-  DevBuf<double> o_res, o_jq, o_jt, o_jx, o_jl, o_himg, o_gimg, o_hpt, o_gpt, o_w, o_jc;
+  DevBuf<double> o_res, o_jq, o_jt, o_jx, o_jl, o_himg, o_gimg, o_hpt, o_gpt, o_w, o_jc, o_hcam, o_gcam, o_ecam, o_wcam;
   BaDev dev() const {
     BaDev d;
     d.cam_model = cam_model.p; d.cam_off = cam_off.p; d.cam_params = cam_params.p;
@@ -490,6 +708,8 @@ struct pcd_ba {
     d.pt_order = pt_order.p; d.slice_start = slice_start.p; d.sell_img = sell_img.p; d.sell_xy = sell_xy.p;
     d.pt_lidar_start = pt_lidar_start.p; d.pt_lidar_list = pt_lidar_list.p;
     d.img_obs_start = img_obs_start.p; d.img_pt = img_pt.p; d.img_xy = img_xy.p; d.img_obs = img_obs.p;
+    d.cam_refine = has_refine ? cam_refine.p : nullptr; d.cam_img_start = cam_img_start.p; d.cam_img_list = cam_img_list.p;
+    d.C = C; d.cam_k = (uniform_model >= 0 && uniform_model <= 4) ? cam_num_params(uniform_model) : PCD_CAM_JAC_STRIDE;
     d.I = I; d.P = P; d.nslices = nslices; d.O = O; d.L = L; d.loss_type = loss_type; d.loss_scale = loss_scale;
     return d;
   }
@@ -529,10 +749,6 @@ extern "C" {
 pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
   PCD_REQUIRE(d && out, "null pointer");
   *out = nullptr;
-  if (d->camera_refine) {
-    set_error("refining intrinsics is not implemented (the reference's default holds them constant)");
-    return PCD_ERR_UNSUPPORTED;
-  }
   PCD_REQUIRE(d->num_cameras > 0 && d->cam_model && d->cam_param_offset && d->cam_params, "cameras");
   PCD_REQUIRE(d->num_images > 0 && d->poses && d->image_camera, "images");
   PCD_REQUIRE(d->num_points > 0 && d->points, "points");
@@ -574,6 +790,7 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
   if (d->image_const_pose) { b->has_cpose = true; UP(image_const_pose, d->image_const_pose, b->I); }
   if (d->image_const_tvec) { b->has_ctvec = true; UP(image_const_tvec, d->image_const_tvec, b->I); }
   if (d->point_const) { b->has_cpt = true; UP(point_const, d->point_const, b->P); }
+  if (d->camera_refine) { b->has_refine = true; UP(cam_refine, d->camera_refine, d->cam_params_len); }
 
   std::vector<uint32_t> st, li;
   // ---- per-track sliced ELL in order of track length ----
@@ -628,6 +845,12 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
       img_xy[2 * e + 1] = d->obs_xy[2 * (size_t)o + 1];
     }
     UP(img_obs_start, st.data(), st.size());
+    {  // images of each camera, ascending
+      std::vector<uint32_t> cst, cli;
+      build_csr(d->image_camera, (uint64_t)b->I, b->C, cst, cli);
+      UP(cam_img_start, cst.data(), cst.size());
+      UP(cam_img_list, cli.data(), cli.size());
+    }
     UP(img_obs, li.data(), li.size());
     UP(img_pt, img_pt.data(), img_pt.size());
     UP(img_xy, img_xy.data(), img_xy.size());
@@ -703,6 +926,17 @@ pcd_status pcd_ba_evaluate_device(pcd_ba* b, const pcd_ba_out* o, void* stream) 
     ScopedKernelTimer t("ba_cam_jac", s);
     PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_cam_jac<M>), dim3(div_up(b->O, 256)), dim3(256), 0, s, d, o->jac_cam));
   }
+  if (o->H_cam || o->g_cam || o->E_cam) {
+    PCD_TRY(b->cam_partial.reserve((size_t)b->I * cam_ne(PCD_CAM_JAC_STRIDE)));
+    ScopedKernelTimer t("ba_cameras", s);
+    PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_cameras<M>), dim3(b->I), dim3(256), 0, s, d, b->cam_partial.p));
+    hipLaunchKernelGGL(k_ba_cameras_reduce, dim3(b->C), dim3(256), 0, s, d, b->cam_partial.p, o->H_cam, o->g_cam,
+                       o->E_cam);
+  }
+  if (o->W_cam && b->O) {
+    ScopedKernelTimer t("ba_cam_w", s);
+    PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_cam_w<M>), dim3(div_up(b->O, 256)), dim3(256), 0, s, d, o->W_cam));
+  }
   if ((o->residuals || o->jac_lidar) && b->L) {
     ScopedKernelTimer t("ba_lidar_raw", s);
     hipLaunchKernelGGL(k_ba_lidar_raw, dim3(div_up(b->L, 256)), dim3(256), 0, s, d, o->residuals, o->jac_lidar);
@@ -755,6 +989,10 @@ pcd_status pcd_ba_evaluate(pcd_ba* b, const pcd_ba_out* o) {
       {o->g_pt, &b->o_gpt, 3 * (size_t)b->P, &d.g_pt},
       {o->W, &b->o_w, 18 * b->O, &d.W},
       {o->jac_cam, &b->o_jc, 2 * PCD_CAM_JAC_STRIDE * b->O, &d.jac_cam},
+      {o->H_cam, &b->o_hcam, (size_t)PCD_CAM_JAC_STRIDE * PCD_CAM_JAC_STRIDE * b->C, &d.H_cam},
+      {o->g_cam, &b->o_gcam, (size_t)PCD_CAM_JAC_STRIDE * b->C, &d.g_cam},
+      {o->E_cam, &b->o_ecam, (size_t)PCD_CAM_JAC_STRIDE * 6 * b->I, &d.E_cam},
+      {o->W_cam, &b->o_wcam, (size_t)PCD_CAM_JAC_STRIDE * 3 * b->O, &d.W_cam},
   };
   for (auto& it : items)
     if (it.host) {

@@ -126,6 +126,15 @@ pcd_status pcd_profile_get(pcd_kernel_time* entries, int cap, int* count) {
 static const int kCamNumParams[11] = {3, 4, 4, 5, 8, 8, 12, 5, 4, 5, 12};
 int pcd_camera_num_params(int model_id) { return (model_id >= 0 && model_id < 11) ? kCamNumParams[model_id] : -1; }
 
+pcd_status pcd_camera_param_groups(int model_id, uint8_t* group) {
+  PCD_REQUIRE(group && model_id >= 0 && model_id < 11, "camera model id / null pointer");
+  // base/camera_models.h: models with one focal length (f cx cy ...) and with two (fx fy cx cy ...)
+  const bool single_f = model_id == 0 || model_id == 2 || model_id == 3 || model_id == 8 || model_id == 9;
+  const int nf = single_f ? 1 : 2;
+  for (int k = 0; k < kCamNumParams[model_id]; ++k) group[k] = k < nf ? 0 : (k < nf + 2 ? 1 : 2);
+  return PCD_OK;
+}
+
 pcd_status pcd_search_range_schedule(const int32_t* global_opt_num, uint64_t n, double kd_max, double kd_min,
                                      double drop_speed, double* out) {
   // sfm/incremental_mapper.cc:1159-1163, 1423-1427 (host-side scalar schedule;

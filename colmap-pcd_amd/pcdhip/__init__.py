@@ -69,7 +69,8 @@ CAM_JAC_STRIDE = 12
 
 class BAOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("cost", "residuals", "jac_q", "jac_t", "jac_X", "jac_lidar",
-                                           "H_img", "g_img", "H_pt", "g_pt", "W", "jac_cam")]
+                                           "H_img", "g_img", "H_pt", "g_pt", "W", "jac_cam",
+                                           "H_cam", "g_cam", "E_cam", "W_cam")]
 
 
 class KernelTime(C.Structure):
@@ -89,7 +90,7 @@ ABI_SYMBOLS = [
     "pcd_nn_query", "pcd_nn_query_algo", "pcd_nn_query_device",
     "pcd_associate", "pcd_associate_device", "pcd_nn_winner_payload_device",
     "pcd_associate_from_payload_device", "pcd_search_range_schedule",
-    "pcd_camera_num_params", "pcd_ba_create", "pcd_ba_destroy", "pcd_ba_set_parameters",
+    "pcd_camera_num_params", "pcd_camera_param_groups", "pcd_ba_create", "pcd_ba_destroy", "pcd_ba_set_parameters",
     "pcd_ba_evaluate", "pcd_ba_evaluate_device", "pcd_ba_device_parameters",
     "pcd_profile_enable", "pcd_profile_reset", "pcd_profile_get", "pcd_nn_last_stats",
     "pcd_sift_match", "pcd_sift_match_device",
@@ -401,6 +402,27 @@ class Projector:
         return found, index, dist, l6, cam
 
 
+def camera_param_groups(model_id):
+    """0 focal length / 1 principal point / 2 extra parameter, per parameter of the model"""
+    k = lib().pcd_camera_num_params(int(model_id))
+    g = np.zeros(max(k, 1), np.uint8)
+    L = lib()
+    L.pcd_camera_param_groups.argtypes = [C.c_int, C.c_void_p]
+    _check(L.pcd_camera_param_groups(int(model_id), _vp(g)))
+    return g[:k]
+
+
+def camera_refine_mask(cam_model, refine_focal_length, refine_principal_point, refine_extra_params,
+                       constant_cameras=()):
+    """BundleAdjuster::ParameterizeCameras (optim/bundle_adjustment.cc:1047-1100) as a flat mask over cam_params"""
+    sel = [bool(refine_focal_length), bool(refine_principal_point), bool(refine_extra_params)]
+    out = []
+    for c, m in enumerate(cam_model):
+        g = camera_param_groups(m)
+        out.extend([0] * len(g) if c in constant_cameras else [int(sel[x]) for x in g])
+    return np.array(out, np.uint8)
+
+
 def search_range_schedule(opt_num, kd_max=1.5, kd_min=0.2, drop=0.1):
     opt_num = np.ascontiguousarray(opt_num, np.int32)
     out = np.empty(opt_num.shape[0], np.float64)
@@ -432,7 +454,8 @@ class BA:
 
     def __init__(self, cam_model, cam_params_list, poses, image_camera, points, obs_image, obs_point, obs_xy,
                  lidar_point=None, lidar_abcd=None, lidar_weight=None, image_const_pose=None,
-                 image_const_tvec=None, point_const=None, loss_type=LOSS_TRIVIAL, loss_scale=1.0, device=0):
+                 image_const_tvec=None, point_const=None, loss_type=LOSS_TRIVIAL, loss_scale=1.0, device=0,
+                 camera_refine=None):
         self.cam_model = np.ascontiguousarray(cam_model, np.int32)
         offs, flat = [], []
         for cp in cam_params_list:
@@ -467,6 +490,11 @@ class BA:
         d.num_lidar = nl; d.lidar_point = _vp(self.lidar_point); d.lidar_abcd = _vp(self.lidar_abcd)
         d.lidar_weight = _vp(self.lidar_weight)
         d.loss_type, d.loss_scale = int(loss_type), float(loss_scale)
+        self.camera_refine = None if camera_refine is None else np.ascontiguousarray(camera_refine, np.uint8)
+        if self.camera_refine is not None:
+            assert self.camera_refine.shape[0] == len(self.cam_params)
+            d.camera_refine = _vp(self.camera_refine)
+        self.C = len(self.cam_model)
         h = C.c_void_p()
         self._h = None
         _check(lib().pcd_ba_create(C.byref(d), C.byref(h)))
@@ -492,7 +520,9 @@ class BA:
                              "g_pt")):
         shapes = dict(cost=(1,), residuals=(2 * self.O + self.L,), jac_q=(self.O, 2, 4), jac_t=(self.O, 2, 3),
                       jac_X=(self.O, 2, 3), jac_lidar=(self.L, 3), H_img=(self.I, 6, 6), g_img=(self.I, 6),
-                      H_pt=(self.P, 3, 3), g_pt=(self.P, 3), W=(self.O, 6, 3), jac_cam=(self.O, 2, CAM_JAC_STRIDE))
+                      H_pt=(self.P, 3, 3), g_pt=(self.P, 3), W=(self.O, 6, 3), jac_cam=(self.O, 2, CAM_JAC_STRIDE),
+                      H_cam=(self.C, CAM_JAC_STRIDE, CAM_JAC_STRIDE), g_cam=(self.C, CAM_JAC_STRIDE),
+                      E_cam=(self.I, CAM_JAC_STRIDE, 6), W_cam=(self.O, CAM_JAC_STRIDE, 3))
         out = {k: np.zeros(shapes[k]) for k in want}
         bo = BAOut(*[_vp(out.get(n)) for n, _ in BAOut._fields_])
         _check(lib().pcd_ba_evaluate(self._h, C.byref(bo)))

@@ -142,17 +142,37 @@ class BundleAdjusterHip {
       for (const auto& kv : SortedMap(config_.lidar_maps_)) AddLidarToProblem(kv.first, kv.second, rec);
     if (!(lidar && phrase == OptimazePhrase::WholeMap))   // SetUpAdjustWholeMapByLidar has no such loop (:664-682)
       for (point3D_t pid : Sorted(config_.ConstantPoints())) AddPointToProblem(pid, rec);
+    ParameterizeCameras();
     ParameterizePoints(rec);
   }
 
   size_t NumResiduals() const { return 2 * obs_image_.size() + lidar_point_.size(); }
-  // what ceres::Solver::Summary::num_effective_parameters_reduced counts with constant intrinsics
+  // ceres::Solver::Summary::num_residuals_reduced: residual blocks whose parameter blocks are all constant drop out
+  size_t NumResidualsReduced() const {
+    size_t n = 0;
+    for (size_t o = 0; o < obs_image_.size(); ++o) {
+      const int im = obs_image_[o];
+      if (!image_const_pose_[im] || !point_const_[obs_point_[o]] || CameraVariable(image_cam_[im])) n += 2;
+    }
+    for (int p : lidar_point_) n += point_const_[p] ? 0 : 1;
+    return n;
+  }
+  // ceres::Solver::Summary::num_effective_parameters_reduced: tangent sizes of the variable parameter blocks --
+  // 3 (quaternion) + 3 - #constant tvec entries per variable pose, 3 per variable point, the optimised subset of
+  // each variable camera (ParameterizeCameras)
   size_t NumEffectiveParameters() const {
     size_t n = 0;
     for (size_t i = 0; i < poses_.size() / 7; ++i)
       if (image_used_[i] && !image_const_pose_[i]) n += 3 + 3 - __builtin_popcount(image_const_tvec_[i]);
     for (size_t p = 0; p < points_.size() / 3; ++p) n += point_const_[p] ? 0 : 3;
+    for (uint8_t v : cam_refine_) n += v;
     return n;
+  }
+  bool CameraVariable(int cam_idx) const {
+    const int k = pcd_camera_num_params(cam_model_[cam_idx]);
+    for (int j = 0; j < k; ++j)
+      if (cam_refine_[cam_off_[cam_idx] + j]) return true;
+    return false;
   }
   size_t NumConstantPoints() const { size_t n = 0; for (uint8_t c : point_const_) n += c; return n; }
 
@@ -172,6 +192,9 @@ class BundleAdjusterHip {
     d.num_lidar = lidar_point_.size(); d.lidar_point = lidar_point_.data(); d.lidar_abcd = lidar_abcd_.data();
     d.lidar_weight = lidar_w_.data();
     d.loss_type = options_.loss_function_type; d.loss_scale = options_.loss_function_scale;
+    bool any_refined = false;
+    for (uint8_t v : cam_refine_) any_refined |= v != 0;
+    d.camera_refine = any_refined ? cam_refine_.data() : nullptr;   // NULL: intrinsics constant (the fork's default)
     return pcd_ba_create(&d, &ba_) == PCD_OK;
   }
   pcd_ba* handle() const { return ba_; }
@@ -180,6 +203,8 @@ class BundleAdjusterHip {
   std::vector<int32_t> cam_model_, cam_off_, image_cam_, obs_image_, obs_point_, lidar_point_;
   std::vector<double> cam_params_, poses_, points_, obs_xy_, lidar_abcd_, lidar_w_;
   std::vector<uint8_t> image_const_pose_, image_const_tvec_, point_const_, image_used_;
+  std::vector<uint8_t> cam_refine_;      // per entry of cam_params_: 1 = optimised (pcd_ba_desc.camera_refine)
+  std::vector<camera_t> camera_ids_;     // flat index -> id
   std::vector<image_t> image_ids_;       // flat index -> id
   std::vector<point3D_t> point_ids_;
 
@@ -199,6 +224,7 @@ class BundleAdjusterHip {
     lidar_point_.clear(); cam_params_.clear(); poses_.clear(); points_.clear(); obs_xy_.clear();
     lidar_abcd_.clear(); lidar_w_.clear(); image_const_pose_.clear(); image_const_tvec_.clear();
     point_const_.clear(); image_used_.clear(); image_ids_.clear(); point_ids_.clear();
+    cam_refine_.clear(); camera_ids_.clear();
     cam_index_.clear(); image_index_.clear(); point_index_.clear(); point3D_num_observations_.clear();
   }
   int CameraIndex(camera_t id, const Reconstruction* rec) {
@@ -207,6 +233,7 @@ class BundleAdjusterHip {
     const Camera& c = rec->cameras.at(id);
     const int idx = (int)cam_model_.size();
     cam_index_[id] = idx;
+    camera_ids_.push_back(id);
     cam_model_.push_back(c.model_id);
     cam_off_.push_back((int32_t)cam_params_.size());
     cam_params_.insert(cam_params_.end(), c.params.begin(), c.params.end());
@@ -270,6 +297,7 @@ class BundleAdjusterHip {
       if (config_.HasImage(te.image_id)) continue;
       point3D_num_observations_[pid] += 1;
       Image& image = rec->images.at(te.image_id);
+      if (cam_index_.count(image.camera_id) == 0) config_.SetConstantCamera(image.camera_id);   // :951-954
       const int ii = ImageIndex(te.image_id, rec, /*const_pose_block=*/true);
       AddObservation(ii, PointIndex(pid, rec), image.points2D.at(te.point2D_idx).xy);
     }
@@ -285,6 +313,23 @@ class BundleAdjusterHip {
     lidar_point_.push_back(PointIndex(pid, rec));
     lidar_abcd_.insert(lidar_abcd_.end(), lp.abcd.begin(), lp.abcd.end());
     lidar_w_.push_back(w);
+  }
+  // :1047-1100: which camera parameters are optimised
+  void ParameterizeCameras() {
+    const bool constant_camera =
+        !options_.refine_focal_length && !options_.refine_principal_point && !options_.refine_extra_params;
+    cam_refine_.assign(cam_params_.size(), 0);
+    for (size_t c = 0; c < cam_model_.size(); ++c) {
+      if (constant_camera || config_.IsConstantCamera(camera_ids_[c])) continue;   // SetParameterBlockConstant
+      uint8_t group[PCD_CAM_JAC_STRIDE];
+      if (pcd_camera_param_groups(cam_model_[c], group) != PCD_OK) continue;
+      const int k = pcd_camera_num_params(cam_model_[c]);
+      for (int j = 0; j < k; ++j) {                                                // SubsetManifold for the rest
+        const bool refine = group[j] == 0 ? options_.refine_focal_length
+                          : group[j] == 1 ? options_.refine_principal_point : options_.refine_extra_params;
+        cam_refine_[cam_off_[c] + j] = refine ? 1 : 0;
+      }
+    }
   }
   // :1107-1131
   void ParameterizePoints(const Reconstruction* rec) {

@@ -81,21 +81,49 @@ static void TestConfigNumObservations() {   // [ref] bundle_adjustment_test.cc:1
   CHECK_EQ(config.NumResiduals(rec), 800u);
 }
 
-static void TestTwoView() {   // bundle_adjustment_test.cc:212-238: [ref] 400 residuals; 309 params = 305 + 4 camera
+// The reference's BA tests were written for upstream COLMAP's defaults refine_focal_length = true,
+// refine_principal_point = false, refine_extra_params = true; this fork defaults all three to false
+// (optim/bundle_adjustment.h:73-81), so the [ref] counts are reproduced with the upstream values set explicitly
+// and the fork's own defaults are checked beside them.
+static BundleAdjustmentOptions UpstreamOptions() {
+  BundleAdjustmentOptions o;
+  o.refine_focal_length = true; o.refine_principal_point = false; o.refine_extra_params = true;
+  return o;
+}
+
+static void TestTwoView() {   // [ref] bundle_adjustment_test.cc:212-245: 400 residuals, 309 parameters
   Reconstruction rec;
   GenerateReconstruction(2, 100, &rec);
   BundleAdjustmentConfig config;
   config.AddImage(0); config.AddImage(1);
   config.SetConstantPose(0);
   config.SetConstantTvec(1, {0});
-  BundleAdjusterHip ba(BundleAdjustmentOptions(), config);
+  BundleAdjusterHip ba(UpstreamOptions(), config);
   ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
   CHECK_EQ(ba.NumResiduals(), 400u);
-  CHECK_EQ(ba.NumEffectiveParameters(), 305u);   // 100*3 points + 3 (quaternion tangent) + 2 (tvec y,z)
+  CHECK_EQ(ba.NumResidualsReduced(), 400u);      // [ref]
+  CHECK_EQ(ba.NumEffectiveParameters(), 309u);   // [ref] 100 x 3 + 5 (pose of image 1) + 2 x 2 (f, k of each camera)
   CHECK_EQ(ba.NumConstantPoints(), 0u);
+  BundleAdjusterHip fork(BundleAdjustmentOptions(), config);   // the fork's defaults: intrinsics constant
+  fork.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
+  CHECK_EQ(fork.NumEffectiveParameters(), 305u);
 }
 
-static void TestPartiallyContainedTracks() {   // bundle_adjustment_test.cc:282-323
+static void TestTwoViewConstantCamera() {   // [ref] bundle_adjustment_test.cc:247-285: 400 / 302
+  Reconstruction rec;
+  GenerateReconstruction(2, 100, &rec);
+  BundleAdjustmentConfig config;
+  config.AddImage(0); config.AddImage(1);
+  config.SetConstantPose(0); config.SetConstantPose(1);
+  config.SetConstantCamera(0);
+  BundleAdjusterHip ba(UpstreamOptions(), config);
+  ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
+  CHECK_EQ(ba.NumResidualsReduced(), 400u);      // [ref]
+  CHECK_EQ(ba.NumEffectiveParameters(), 302u);   // [ref] 100 x 3 + 2 parameters of camera 1
+  CHECK(!ba.CameraVariable(0) && ba.CameraVariable(1));
+}
+
+static void TestPartiallyContainedTracks() {   // [ref] bundle_adjustment_test.cc:287-328: 400 / 7
   Reconstruction rec;
   GenerateReconstruction(3, 100, &rec);
   const point3D_t variable_point = rec.images[2].points2D[0].point3D_id;
@@ -103,15 +131,20 @@ static void TestPartiallyContainedTracks() {   // bundle_adjustment_test.cc:282-
   BundleAdjustmentConfig config;
   config.AddImage(0); config.AddImage(1);
   config.SetConstantPose(0); config.SetConstantPose(1);
-  BundleAdjusterHip ba(BundleAdjustmentOptions(), config);
+  BundleAdjusterHip ba(UpstreamOptions(), config);
   ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
-  CHECK_EQ(ba.NumResiduals(), 400u);            // [ref] 400
+  CHECK_EQ(ba.NumResiduals(), 400u);
+  CHECK_EQ(ba.NumResidualsReduced(), 400u);     // [ref] (the camera blocks keep every residual in)
   CHECK_EQ(ba.NumConstantPoints(), 99u);        // every track that also lives in image 2 is held constant (:1107-1131)
-  CHECK_EQ(ba.NumEffectiveParameters(), 3u);    // [ref] 7 = 3 + 4 camera parameters
+  CHECK_EQ(ba.NumEffectiveParameters(), 7u);    // [ref] 1 x 3 point + 2 x 2 camera parameters
   for (size_t i = 0; i < ba.point_ids_.size(); ++i) CHECK((ba.point_ids_[i] == variable_point) == (ba.point_const_[i] == 0));
+  BundleAdjusterHip fork(BundleAdjustmentOptions(), config);
+  fork.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
+  CHECK_EQ(fork.NumEffectiveParameters(), 3u);
+  CHECK_EQ(fork.NumResidualsReduced(), 4u);     // only the two observations of the one variable point remain
 }
 
-static void TestForceToOptimizePoint() {   // bundle_adjustment_test.cc:325-380
+static void TestForceToOptimizePoint() {   // [ref] bundle_adjustment_test.cc:330-392: 402 / 10
   Reconstruction rec;
   GenerateReconstruction(3, 100, &rec);
   const point3D_t add_variable = rec.images[2].points2D[1].point3D_id;
@@ -122,13 +155,73 @@ static void TestForceToOptimizePoint() {   // bundle_adjustment_test.cc:325-380
   config.SetConstantPose(0); config.SetConstantPose(1);
   config.AddVariablePoint(add_variable);
   config.AddConstantPoint(add_constant);
-  BundleAdjusterHip ba(BundleAdjustmentOptions(), config);
+  BundleAdjusterHip ba(UpstreamOptions(), config);
   ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
-  // un-reduced: 400 + 2 (variable point seen from image 2) + 2 (constant point seen from image 2);
-  // [ref] 402 is Ceres' *reduced* count, which drops the all-constant block of the constant point
+  // un-reduced: 400 + 2 (variable point seen from image 2) + 2 (constant point seen from image 2)
   CHECK_EQ(ba.NumResiduals(), 404u);
-  CHECK_EQ(ba.NumEffectiveParameters(), 6u);    // [ref] 10 = 6 + 4 camera parameters
+  // [ref] 402: the block of the constant point in image 2 has only constant parameters (camera 2 is made constant
+  // when AddPointToProblem meets it, :951-954) and is dropped
+  CHECK_EQ(ba.NumResidualsReduced(), 402u);
+  CHECK_EQ(ba.NumEffectiveParameters(), 10u);   // [ref] 2 x 3 points + 2 x 2 camera parameters
   CHECK_EQ(ba.NumConstantPoints(), 98u);
+  CHECK(ba.cam_model_.size() == 3 && !ba.CameraVariable(2));
+}
+
+static void TestConstantPoints() {   // [ref] bundle_adjustment_test.cc:394-440: 400 / 298
+  Reconstruction rec;
+  GenerateReconstruction(2, 100, &rec);
+  BundleAdjustmentConfig config;
+  config.AddImage(0); config.AddImage(1);
+  config.SetConstantPose(0); config.SetConstantPose(1);
+  config.AddConstantPoint(1); config.AddConstantPoint(2);
+  BundleAdjusterHip ba(UpstreamOptions(), config);
+  ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
+  CHECK_EQ(ba.NumResidualsReduced(), 400u);      // [ref]
+  CHECK_EQ(ba.NumEffectiveParameters(), 298u);   // [ref] 98 x 3 + 2 x 2
+  CHECK_EQ(ba.NumConstantPoints(), 2u);
+  for (size_t i = 0; i < ba.point_ids_.size(); ++i)
+    CHECK((ba.point_ids_[i] == 1 || ba.point_ids_[i] == 2) == (ba.point_const_[i] != 0));
+}
+
+static void TestVariableImage() {   // [ref] bundle_adjustment_test.cc:442-484: 600 / 317
+  Reconstruction rec;
+  GenerateReconstruction(3, 100, &rec);
+  BundleAdjustmentConfig config;
+  config.AddImage(0); config.AddImage(1); config.AddImage(2);
+  config.SetConstantPose(0);
+  config.SetConstantTvec(1, {0});
+  BundleAdjusterHip ba(UpstreamOptions(), config);
+  ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
+  CHECK_EQ(ba.NumResidualsReduced(), 600u);      // [ref]
+  CHECK_EQ(ba.NumEffectiveParameters(), 317u);   // [ref] 100 x 3 + 5 + 6 + 3 x 2
+  CHECK(ba.image_const_pose_[0] == 1 && ba.image_const_tvec_[1] == 1 && ba.image_const_pose_[2] == 0 && ba.image_const_tvec_[2] == 0);
+}
+
+static void TestCameraParameterGroups() {   // [ref] bundle_adjustment_test.cc:486-657: 307 / 313 / 307
+  for (int variant = 0; variant < 3; ++variant) {
+    Reconstruction rec;
+    GenerateReconstruction(2, 100, &rec);
+    BundleAdjustmentConfig config;
+    config.AddImage(0); config.AddImage(1);
+    config.SetConstantPose(0);
+    config.SetConstantTvec(1, {0});
+    BundleAdjustmentOptions o = UpstreamOptions();
+    if (variant == 0) o.refine_focal_length = false;      // TestConstantFocalLength
+    if (variant == 1) o.refine_principal_point = true;    // TestVariablePrincipalPoint
+    if (variant == 2) o.refine_extra_params = false;      // TestConstantExtraParam
+    BundleAdjusterHip ba(o, config);
+    ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::NoLidar);
+    CHECK_EQ(ba.NumResidualsReduced(), 400u);   // [ref]
+    CHECK_EQ(ba.NumEffectiveParameters(), variant == 1 ? 313u : 307u);   // [ref] 305 + 2 / + 8 / + 2
+    // SIMPLE_RADIAL f cx cy k: which entries of each camera are optimised
+    for (int c = 0; c < 2; ++c) {
+      const uint8_t* m = ba.cam_refine_.data() + ba.cam_off_[c];
+      CHECK_EQ((int)m[0], variant == 0 ? 0 : 1);
+      CHECK_EQ((int)m[1], variant == 1 ? 1 : 0);
+      CHECK_EQ((int)m[2], variant == 1 ? 1 : 0);
+      CHECK_EQ((int)m[3], variant == 2 ? 0 : 1);
+    }
+  }
 }
 
 static void TestLidarBlocks() {   // optim/bundle_adjustment.cc:993-1040 weights / NaN guard, :601-682 phrases
@@ -429,6 +522,10 @@ static int TestGpu() {
 int main(int argc, char** argv) {
   TestConfigNumObservations();
   TestTwoView();
+  TestTwoViewConstantCamera();
+  TestConstantPoints();
+  TestVariableImage();
+  TestCameraParameterGroups();
   TestPartiallyContainedTracks();
   TestForceToOptimizePoint();
   TestLidarBlocks();

@@ -257,6 +257,11 @@ typedef enum {
   PCD_CAM_SIMPLE_RADIAL_FISHEYE = 8, PCD_CAM_RADIAL_FISHEYE = 9, PCD_CAM_THIN_PRISM_FISHEYE = 10
 } pcd_camera_model;
 int pcd_camera_num_params(int model_id);   /* -1 for an unknown id */
+/* Parameter groups of a model (base/camera_models.h FocalLengthIdxs / PrincipalPointIdxs / ExtraParamsIdxs):
+ * group[k] = 0 focal length, 1 principal point, 2 extra (distortion) parameter, for k < num_params.
+ * BundleAdjuster::ParameterizeCameras (optim/bundle_adjustment.cc:1047-1100) holds a group constant unless
+ * refine_focal_length / refine_principal_point / refine_extra_params is set. */
+pcd_status pcd_camera_param_groups(int model_id, uint8_t* group /*[num_params]*/);
 
 /* Flat problem description (all host pointers, copied at create).
  * It is what BundleAdjuster::SetUp*ByLidar assembles block by block:
@@ -270,9 +275,10 @@ int pcd_camera_num_params(int model_id);   /* -1 for an unknown id */
  * image is outside the config (:967-983): such blocks use the constant-pose functor.
  * image_const_tvec[i] bit k = tvec[k] held constant (SetSubsetManifold :912-915).
  * point_const[p] = ParameterizePoints (:1107-1131).
- * Intrinsics are held constant in the normal-equation outputs (ba_refine_* default false,
- * controllers/incremental_mapper.h:156-158); camera_refine != NULL (camera blocks in H/g) is
- * PCD_ERR_UNSUPPORTED.  The raw path serves refined intrinsics through pcd_ba_out.jac_cam. */
+ * camera_refine = what ParameterizeCameras (:1047-1100) decides: one byte per entry of cam_params, 1 = the
+ * parameter is optimised, 0 = held constant (SetParameterBlockConstant for a whole camera, SubsetManifold for
+ * part of one).  NULL = all intrinsics constant (this fork's default, ba_refine_* = false,
+ * controllers/incremental_mapper.h:156-158): the camera outputs of pcd_ba_out are then zero. */
 typedef struct {
   int32_t device;
   int32_t num_cameras;
@@ -298,7 +304,7 @@ typedef struct {
   const double* lidar_weight;      /* [L]                        */
   int32_t loss_type;               /* pcd_loss_type              */
   double loss_scale;
-  const uint8_t* camera_refine;    /* must be NULL               */
+  const uint8_t* camera_refine;    /* [cam_params_len] or NULL   */
   int32_t reserved[8];
 } pcd_ba_desc;
 
@@ -337,6 +343,16 @@ typedef struct {
   double* g_pt;
   double* W;
   double* jac_cam;     /* [O][2][PCD_CAM_JAC_STRIDE] d r / d camera params, see above */
+  /* Camera blocks of the normal equations (refined intrinsics, desc.camera_refine): loss-corrected, columns of
+   * constant parameters zero, S = PCD_CAM_JAC_STRIDE rows / columns per camera (entries >= K zero):
+   *   H_cam [C][S][S] = sum Jc^T Jc    g_cam [C][S] = sum Jc^T r      over the observations of the camera's images
+   *   E_cam [I][S][6] = sum Jc^T Jp    camera x pose-tangent coupling of each image (an image has one camera)
+   *   W_cam [O][S][3] = Jc^T JX        camera x point coupling of each observation
+   * Together with H_img, g_img, H_pt, g_pt, W this is the full J^T J / J^T r of the problem in block form. */
+  double* H_cam;
+  double* g_cam;
+  double* E_cam;
+  double* W_cam;
 } pcd_ba_out;
 
 pcd_status pcd_ba_evaluate(pcd_ba* ba, const pcd_ba_out* out);                 /* host outputs   */

@@ -353,6 +353,58 @@ void oracle_ba_evaluate_raw(const oracle_ba_problem* p, double* residuals, doubl
   }
 }
 
+// Camera blocks of the normal equations with refined intrinsics (ParameterizeCameras,
+// optim/bundle_adjustment.cc:1047-1100): refine[cam_param_off[c] + k] = 1 when parameter k of camera c is
+// optimised; the columns of constant parameters vanish (whole block constant, or SubsetManifold).
+//   Hcam [C][S][S] = sum Jc^T Jc, gcam [C][S] = sum Jc^T r   over the observations of the camera's images
+//   Ecam [I][S][6] = sum Jc^T Jp   (pose tangent as in oracle_ba_normal_equations)
+//   Wcam [O][S][3] = Jc^T JX       per observation              S = cam_jac_stride; any output may be NULL
+void oracle_ba_camera_blocks(const oracle_ba_problem* p, const uint8_t* refine, double* Hcam, double* gcam,
+                             double* Ecam, double* Wcam) {
+  const int S = p->cam_jac_stride;
+  if (Hcam) std::memset(Hcam, 0, sizeof(double) * S * S * (size_t)p->num_cameras);
+  if (gcam) std::memset(gcam, 0, sizeof(double) * S * (size_t)p->num_cameras);
+  if (Ecam) std::memset(Ecam, 0, sizeof(double) * S * 6 * (size_t)p->num_images);
+  if (Wcam) std::memset(Wcam, 0, sizeof(double) * S * 3 * (size_t)p->num_obs);
+  for (int64_t o = 0; o < p->num_obs; ++o) {
+    const int im = p->obs_image[o], pt = p->obs_point[o], cm = p->image_camera[im];
+    const int model = p->cam_model[cm], K = kNumParams[model];
+    const double* pose = p->poses + 7 * (size_t)im;
+    double r[2], jq[8], jt[6], jx[6], jc[24];
+    eval_reproj_dispatch(model, pose, pose + 4, p->points + 3 * (size_t)pt, p->cam_params + p->cam_param_off[cm],
+                         p->obs_xy[2 * o], p->obs_xy[2 * o + 1], r, jq, jt, jx, jc);
+    double rho[3];
+    loss_evaluate(p->loss_type, p->loss_scale, r[0] * r[0] + r[1] * r[1], rho);
+    const double sr = std::sqrt(rho[1]);
+    const bool cpose = p->image_const_pose && p->image_const_pose[im];
+    const bool cpt = p->point_const && p->point_const[pt];
+    const unsigned tmask = (p->image_const_tvec ? p->image_const_tvec[im] : 0);
+    double plus[12], Jp[12], Jx[6], Jc[24];
+    quat_plus_jacobian(pose, plus);
+    for (int row = 0; row < 2; ++row) {
+      for (int c = 0; c < 3; ++c) {
+        double acc = 0;
+        for (int k = 0; k < 4; ++k) acc += jq[row * 4 + k] * plus[k * 3 + c];
+        Jp[row * 6 + c] = cpose ? 0.0 : sr * acc;
+        Jp[row * 6 + 3 + c] = (cpose || ((tmask >> c) & 1)) ? 0.0 : sr * jt[row * 3 + c];
+      }
+      for (int c = 0; c < 3; ++c) Jx[row * 3 + c] = cpt ? 0.0 : sr * jx[row * 3 + c];
+      for (int k = 0; k < K; ++k)
+        Jc[row * 12 + k] = (refine && refine[p->cam_param_off[cm] + k]) ? sr * jc[row * K + k] : 0.0;
+    }
+    const double rc[2] = {sr * r[0], sr * r[1]};
+    for (int a = 0; a < K; ++a) {
+      if (Hcam) for (int b = 0; b < K; ++b)
+        Hcam[((size_t)cm * S + a) * S + b] += Jc[a] * Jc[b] + Jc[12 + a] * Jc[12 + b];
+      if (gcam) gcam[(size_t)cm * S + a] += Jc[a] * rc[0] + Jc[12 + a] * rc[1];
+      if (Ecam) for (int b = 0; b < 6; ++b)
+        Ecam[((size_t)im * S + a) * 6 + b] += Jc[a] * Jp[b] + Jc[12 + a] * Jp[6 + b];
+      if (Wcam) for (int b = 0; b < 3; ++b)
+        Wcam[((size_t)o * S + a) * 3 + b] = Jc[a] * Jx[b] + Jc[12 + a] * Jx[3 + b];
+    }
+  }
+}
+
 // Residual-only evaluation: what each CostFunction::Evaluate(parameters, residuals, nullptr) returns when
 // Ceres evaluates a trial step -- the functors instantiated with plain doubles, no Jets.
 void oracle_ba_residuals(const oracle_ba_problem* p, double* residuals) {

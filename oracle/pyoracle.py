@@ -382,6 +382,25 @@ class BA:
         with ThreadPoolExecutor(nthreads) as ex:
             return 0.5 * sum(ex.map(run, work))
 
+    def camera_blocks(self, refine, want_w=False):
+        """refine: uint8 [len(cam_params)] (1 = optimised).  Returns H_cam [C][S][S], g_cam [C][S], E_cam [I][S][6],
+        W_cam [O][S][3] or None -- with S = 12 (the C ABI's PCD_CAM_JAC_STRIDE)."""
+        S = 12
+        keep = self._p.cam_jac_stride
+        self._p.cam_jac_stride = S
+        C_, I, O = len(self.cam_model), self.poses.shape[0], len(self.obs_image)
+        refine = np.ascontiguousarray(refine, np.uint8)
+        assert refine.shape[0] == len(self.cam_params)
+        H = np.zeros((C_, S, S)); g = np.zeros((C_, S)); E = np.zeros((I, S, 6))
+        W = np.zeros((O, S, 3)) if want_w else None
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        L = lib()
+        L.oracle_ba_camera_blocks.restype = None
+        L.oracle_ba_camera_blocks.argtypes = [C.POINTER(BAProblem)] + [C.c_void_p] * 5
+        L.oracle_ba_camera_blocks(C.byref(self._p), vp(refine), vp(H), vp(g), vp(E), vp(W))
+        self._p.cam_jac_stride = keep
+        return H, g, E, W
+
     def observation_errors(self):
         O = len(self.obs_image)
         sq = np.zeros(O)

@@ -142,3 +142,45 @@ def test_midsize_scene_properties(gpu, oracle):
     ob = oracle.BA(**s)
     _close(res, ob.evaluate_raw()[0], 1e-9, "residuals vs oracle")
     ba.close()
+
+
+@pytest.mark.parametrize("model", [2, 4, 6, 9])
+def test_camera_blocks(gpu, oracle, model):
+    """refined intrinsics (ParameterizeCameras, optim/bundle_adjustment.cc:1047-1100): camera blocks of the normal
+    equations vs the oracle's accumulation of its Jet Jacobians, with the focal / principal-point / extra-parameter
+    subsets of bundle_adjustment_test.cc:479-645, a constant camera, constant poses / tvec entries / points and a
+    robust loss.  Models 2 and 4 take the compiled-in kernels, 6 and 9 the generic (per-observation switch) path."""
+    rng = np.random.default_rng(300 + model)
+    s = _scene(model, rng, I=7, P=400)
+    # three cameras of this model with different parameters; camera 1 constant (SetConstantCamera)
+    cam = np.array(s["cam_params_list"][0], np.float64)
+    s["cam_model"] = np.array([model] * 3, np.int32)
+    s["cam_params_list"] = [cam, cam * (1 + 1e-3), cam * (1 - 2e-3)]
+    s["image_camera"] = (np.arange(7) % 3).astype(np.int32)
+    tv = np.zeros(7, np.uint8); tv[3] = 0b001
+    pc = np.zeros(400, np.uint8); pc[::7] = 1
+    kw = dict(image_const_tvec=tv, point_const=pc, loss_type=1, loss_scale=2.0)
+    for flags in [(True, False, True), (False, False, True), (True, True, True), (True, False, False)]:
+        mask = gpu.camera_refine_mask(s["cam_model"], *flags, constant_cameras=(1,))
+        ob = oracle.BA(**s, **kw)
+        H, g, E, W = ob.camera_blocks(mask, want_w=True)
+        ba = gpu.BA(**s, **kw, camera_refine=mask)
+        got = ba.evaluate(("H_cam", "g_cam", "E_cam", "W_cam", "H_img", "cost"))
+        _close(got["H_cam"], H, 1e-9, f"H_cam {flags}")
+        _close(got["g_cam"], g, 1e-9, f"g_cam {flags}")
+        _close(got["E_cam"], E, 1e-9, f"E_cam {flags}")
+        _close(got["W_cam"], W, 1e-9, f"W_cam {flags}")
+        assert np.abs(H[0]).max() > 0 and not got["H_cam"][1].any() and not got["E_cam"][1::3].any()
+        # constant parameters have empty rows / columns
+        const = np.nonzero(mask[:len(cam)] == 0)[0]
+        assert not got["H_cam"][0][const].any() and not got["H_cam"][0][:, const].any()
+        again = ba.evaluate(("H_cam", "g_cam"))
+        assert np.array_equal(again["H_cam"], got["H_cam"]) and np.array_equal(again["g_cam"], got["g_cam"])
+        # the pose blocks do not depend on the camera mask
+        _close(got["H_img"], ob.normal_equations()[1], 1e-9, "H_img")
+        ba.close()
+    # no mask: intrinsics constant (this fork's default), camera outputs zero
+    ba = gpu.BA(**s, **kw)
+    got = ba.evaluate(("H_cam", "g_cam", "E_cam"))
+    assert not got["H_cam"].any() and not got["g_cam"].any() and not got["E_cam"].any()
+    ba.close()

@@ -234,3 +234,38 @@ def test_normal_equations_consistency(oracle):
         assert abs(cost - c2) <= 1e-12 * abs(c2)
         for a, b in ((Himg, H2), (gimg, g2), (Hpt, P2), (gpt, p2)):
             np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-7)
+
+
+def test_camera_blocks_consistency(oracle):
+    """camera blocks (refined intrinsics, optim/bundle_adjustment.cc:1047-1100) = Jc^T [Jc | Jp | JX | r] re-assembled
+    with numpy from the raw Jet blocks, the loss and the parameter mask."""
+    s = synth.ba_scene(5, 120, seed=9, const_pose_frac=0.2)
+    s["cam_model"] = np.array([4, 4], np.int32)
+    s["cam_params_list"] = [synth.OPENCV_PARAMS, [3000.0, 3010.0, 2000.0, 1500.0, -0.04, 0.02, 2e-4, -1e-4]]
+    s["image_camera"] = np.array([0, 1, 0, 1, 0], np.int32)
+    tv = np.zeros(5, np.uint8); tv[2] = 0b100
+    pc = np.zeros(120, np.uint8); pc[::9] = 1
+    ba = oracle.BA(**s, image_const_tvec=tv, point_const=pc, loss_type=2, loss_scale=3.0)
+    mask = np.array([1, 1, 0, 0, 1, 1, 1, 1] + [0] * 8, np.uint8)      # camera 0: f + extra; camera 1 constant
+    H, g, E, W = ba.camera_blocks(mask, want_w=True)
+    res, Jq, Jt, JX, Jc, JL = ba.evaluate_raw()
+    H2 = np.zeros_like(H); g2 = np.zeros_like(g); E2 = np.zeros_like(E)
+    for o in range(len(ba.obs_image)):
+        im, pt = ba.obs_image[o], ba.obs_point[o]
+        cm = ba.image_camera[im]
+        r = res[2 * o:2 * o + 2]
+        rho = oracle.loss(2, 3.0, r @ r)
+        sr = np.sqrt(rho[1])
+        x = ba.poses[im, :4]
+        plus = np.array([[-x[1], -x[2], -x[3]], [x[0], x[3], -x[2]], [-x[3], x[0], x[1]], [x[2], -x[1], x[0]]])
+        Jp = np.concatenate([Jq[o] @ plus, Jt[o]], axis=1) * sr
+        if ba.image_const_pose[im]: Jp[:] = 0
+        for k in range(3):
+            if (tv[im] >> k) & 1: Jp[:, 3 + k] = 0
+        Jx = JX[o] * sr * (0 if pc[pt] else 1)
+        J = np.zeros((2, 12)); J[:, :8] = Jc[o][:, :8] * sr * mask[8 * cm:8 * cm + 8]
+        H2[cm] += J.T @ J; g2[cm] += J.T @ (sr * r); E2[im] += J.T @ Jp
+        np.testing.assert_allclose(W[o], J.T @ Jx, rtol=1e-12, atol=1e-6)
+    for a, b in ((H, H2), (g, g2), (E, E2)):
+        np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-6)
+    assert np.abs(H[0]).max() > 0 and not H[1].any() and not H[0][2:4].any()
