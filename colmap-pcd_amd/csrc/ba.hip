@@ -681,7 +681,7 @@ using namespace pcd;
 struct pcd_ba {
   int device = 0;
   int C = 0, I = 0, P = 0, nslices = 0;
-  uint64_t O = 0, L = 0;
+  uint64_t O = 0, L = 0, cam_params_len = 0;
   int loss_type = 0;
   double loss_scale = 1.0;
   int uniform_model = -1;  // >= 0: every camera has this model
@@ -777,6 +777,7 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
   b->device = d->device;
   b->C = d->num_cameras; b->I = d->num_images; b->P = d->num_points; b->O = d->num_obs; b->L = d->num_lidar;
   b->loss_type = d->loss_type; b->loss_scale = d->loss_scale;
+  b->cam_params_len = d->cam_params_len;
   b->uniform_model = d->cam_model[0];
   for (int c = 1; c < d->num_cameras; ++c)
     if (d->cam_model[c] != b->uniform_model) b->uniform_model = -1;
@@ -874,6 +875,13 @@ pcd_status pcd_ba_set_parameters(pcd_ba* b, const double* poses, const double* p
   PCD_HIP_TRY(hipSetDevice(b->device));
   if (poses) PCD_HIP_TRY(hipMemcpy(b->poses.p, poses, 7 * (size_t)b->I * sizeof(double), hipMemcpyHostToDevice));
   if (points) PCD_HIP_TRY(hipMemcpy(b->points.p, points, 3 * (size_t)b->P * sizeof(double), hipMemcpyHostToDevice));
+  return PCD_OK;
+}
+
+pcd_status pcd_ba_set_camera_parameters(pcd_ba* b, const double* cam_params) {
+  PCD_REQUIRE(b && cam_params, "null pointer");
+  PCD_HIP_TRY(hipSetDevice(b->device));
+  PCD_HIP_TRY(hipMemcpy(b->cam_params.p, cam_params, b->cam_params_len * sizeof(double), hipMemcpyHostToDevice));
   return PCD_OK;
 }
 

@@ -49,6 +49,7 @@ struct pcd_cloud {
   pcd::GridParams grid{};
   pcd::PyramidParams pyr{};
   uint64_t ncells = 0, nblocks = 0, occupied = 0;
+  float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};   // tight bounds of the finite rows (valid when m > 0)
   double build_ms = 0;
   pcd::QueryScratch* scratch = nullptr;
 };

@@ -238,6 +238,7 @@ static pcd_status build_grid(pcd_cloud* c, float user_h, hipStream_t s) {
   c->m = hc[0];
   float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   if (c->m) for (int d = 0; d < 3; ++d) { lo[d] = ord2f(hb[d]); hi[d] = ord2f(hb[3 + d]); }
+  for (int d = 0; d < 3; ++d) { c->bb_lo[d] = lo[d]; c->bb_hi[d] = hi[d]; }
 
   // --- cell size: user value, or iterate towards kTargetOcc points per occupied cell ---
   double ext[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
@@ -459,6 +460,7 @@ pcd_status pcd_cloud_get_info(const pcd_cloud* c, pcd_cloud_info* info) {
   info->num_indexed = c->m;
   info->occupied_cells = c->occupied;
   info->build_ms = c->build_ms;
+  for (int d = 0; d < 3; ++d) { info->bbox_lo[d] = c->bb_lo[d]; info->bbox_hi[d] = c->bb_hi[d]; }
   return PCD_OK;
 }
 

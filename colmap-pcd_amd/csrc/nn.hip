@@ -86,6 +86,27 @@ __global__ void k_prepare_queries(const double* __restrict__ q, uint64_t Q, floa
   keys[i] = kKeyInit;
 }
 
+// pcd_nn_refine_device: the keys come in with another shard's results.  A query stays active only if this shard
+// can still improve it: lower bound of the float distance to the shard's tight bounding box <= incoming distance
+// (monotone rounding: fl_dist(q, p) >= fl_dist(q, clamp(q, lo, hi)) for every p in the box; equality is kept --
+// a lower index at the same distance may live here).  Inactive queries get w = 0 and no kernel touches their key.
+__global__ void k_prepare_refine(const double* __restrict__ q, uint64_t Q, const uint8_t* __restrict__ skip,
+                                 float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                 float4* __restrict__ qf4, uint64_t* __restrict__ keys) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  float x = (float)q[3 * i], y = (float)q[3 * i + 1], z = (float)q[3 * i + 2];
+  bool ok = isfinite(x) && isfinite(y) && isfinite(z) && !(skip && skip[i]);
+  uint64_t k = keys[i];
+  if (k == PCD_KEY_NONE) k = kKeyInit;
+  if (ok) {
+    const float px = fminf(fmaxf(x, lox), hix), py = fminf(fmaxf(y, loy), hiy), pz = fminf(fmaxf(z, loz), hiz);
+    ok = l2_simple3(x, y, z, px, py, pz) <= __uint_as_float((uint32_t)(k >> 32));
+  }
+  qf4[i] = make_float4(x, y, z, ok ? 1.f : 0.f);
+  keys[i] = k;
+}
+
 // keys still at kKeyInit mean "nothing found"
 __global__ void k_finalize_keys(uint64_t* __restrict__ keys, uint64_t Q) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -436,14 +457,18 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
 }
 
 static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int algo, uint64_t* d_keys,
-                            hipStream_t s) {
+                            hipStream_t s, bool refine = false, const uint8_t* d_skip = nullptr) {
   QueryScratch* sc = scratch_of(c);
   if (Q == 0) return PCD_OK;
   PCD_REQUIRE(Q < 0xFFFFFFF0ull, "more than 2^32 queries in one call");
   PCD_TRY(sc->qf4.reserve(Q));
   {
     ScopedKernelTimer t("nn_prepare", s);
-    hipLaunchKernelGGL(k_prepare_queries, dim3(div_up(Q, 256)), dim3(256), 0, s, d_q, Q, sc->qf4.p, d_keys);
+    if (refine)
+      hipLaunchKernelGGL(k_prepare_refine, dim3(div_up(Q, 256)), dim3(256), 0, s, d_q, Q, d_skip, c->bb_lo[0],
+                         c->bb_lo[1], c->bb_lo[2], c->bb_hi[0], c->bb_hi[1], c->bb_hi[2], sc->qf4.p, d_keys);
+    else
+      hipLaunchKernelGGL(k_prepare_queries, dim3(div_up(Q, 256)), dim3(256), 0, s, d_q, Q, sc->qf4.p, d_keys);
   }
   if (c->m > 0) {
     if (algo == PCD_NN_BRUTEFORCE) {
@@ -496,6 +521,14 @@ pcd_status pcd_nn_query_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q, 
   PCD_REQUIRE(Q == 0 || (d_q_xyz && d_keys), "null pointer");
   PCD_HIP_TRY(hipSetDevice(c->device));
   return nn_device(c, d_q_xyz, Q, algo, d_keys, (hipStream_t)stream);
+}
+
+pcd_status pcd_nn_refine_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q, const uint8_t* d_skip,
+                                uint64_t* d_keys, void* stream) {
+  PCD_REQUIRE(c, "null cloud");
+  PCD_REQUIRE(Q == 0 || (d_q_xyz && d_keys), "null pointer");
+  PCD_HIP_TRY(hipSetDevice(c->device));
+  return nn_device(c, d_q_xyz, Q, PCD_NN_AUTO, d_keys, (hipStream_t)stream, /*refine=*/true, d_skip);
 }
 
 pcd_status pcd_nn_query_algo(pcd_cloud* c, const double* q_xyz, uint64_t Q, int algo, uint32_t* idx, float* sqdist,

@@ -41,7 +41,7 @@ class CloudOptions(C.Structure):
 class CloudInfo(C.Structure):
     _fields_ = [("cell_size", C.c_float), ("origin", C.c_float * 3), ("dims", C.c_int32 * 3),
                 ("block_dims", C.c_int32 * 3), ("num_indexed", C.c_uint64), ("occupied_cells", C.c_uint64),
-                ("build_ms", C.c_double)]
+                ("build_ms", C.c_double), ("bbox_lo", C.c_float * 3), ("bbox_hi", C.c_float * 3)]
 
 
 class AssocOut(C.Structure):
@@ -87,10 +87,10 @@ ABI_SYMBOLS = [
     "pcd_last_error", "pcd_version", "pcd_device_count",
     "pcd_cloud_options_default", "pcd_cloud_create", "pcd_cloud_destroy", "pcd_cloud_size",
     "pcd_cloud_get_info", "pcd_cloud_download",
-    "pcd_nn_query", "pcd_nn_query_algo", "pcd_nn_query_device",
+    "pcd_nn_query", "pcd_nn_query_algo", "pcd_nn_query_device", "pcd_nn_refine_device",
     "pcd_associate", "pcd_associate_device", "pcd_nn_winner_payload_device",
     "pcd_associate_from_payload_device", "pcd_search_range_schedule",
-    "pcd_camera_num_params", "pcd_camera_param_groups", "pcd_ba_create", "pcd_ba_destroy", "pcd_ba_set_parameters",
+    "pcd_camera_num_params", "pcd_camera_param_groups", "pcd_ba_create", "pcd_ba_destroy", "pcd_ba_set_parameters", "pcd_ba_set_camera_parameters",
     "pcd_ba_evaluate", "pcd_ba_evaluate_device", "pcd_ba_device_parameters",
     "pcd_profile_enable", "pcd_profile_reset", "pcd_profile_get", "pcd_nn_last_stats",
     "pcd_sift_match", "pcd_sift_match_device",
@@ -238,7 +238,8 @@ class Cloud:
         i = CloudInfo()
         _check(lib().pcd_cloud_get_info(self._h, C.byref(i)))
         return dict(cell_size=i.cell_size, origin=list(i.origin), dims=list(i.dims), block_dims=list(i.block_dims),
-                    num_indexed=i.num_indexed, occupied_cells=i.occupied_cells, build_ms=i.build_ms)
+                    num_indexed=i.num_indexed, occupied_cells=i.occupied_cells, build_ms=i.build_ms,
+                    bbox_lo=list(i.bbox_lo), bbox_hi=list(i.bbox_hi))
 
     def download(self):
         n = len(self)
@@ -259,6 +260,12 @@ class Cloud:
 
     def nn_device(self, d_q, Q, d_keys, algo=NN_AUTO, stream=0):
         _check(lib().pcd_nn_query_device(self._h, _ptr(d_q), Q, algo, _ptr(d_keys), C.c_void_p(stream)))
+
+    def nn_refine_device(self, d_q, Q, d_keys, d_skip=None, stream=0):
+        """second phase of a sharded search: keys in/out (pcd_nn_refine_device)"""
+        L = lib()
+        L.pcd_nn_refine_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.pcd_nn_refine_device(self._h, _ptr(d_q), Q, _ptr(d_skip), _ptr(d_keys), C.c_void_p(stream)))
 
     def associate(self, q, max_range=None, gate_mode=GATE_MAPPER_LOCAL):
         q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)

@@ -1,0 +1,187 @@
+// ceres_adapter.h -- Ceres keeps the solve, the GPU evaluates: the problem BundleAdjuster::SetUp*ByLidar builds
+// (optim/bundle_adjustment.cc:601-682) is handed to Ceres as residual blocks whose CostFunction::Evaluate only COPIES
+// what one batched pcd_ba_evaluate computed for all blocks in PrepareForEvaluation.
+//
+// Replaces, per residual block, the reference's
+//   ceres::AutoDiffCostFunction<BundleAdjustmentCostFunction<Model>, 2, 4, 3, 3, K>              (optim/bundle_adjustment.cc:880-893)
+//   ceres::AutoDiffCostFunction<BundleAdjustmentConstantPoseCostFunction<Model>, 2, 3, K>        (:858-876, :967-983)
+//   ceres::AutoDiffCostFunction<BundleAdjustmentLidarCostFunction, 1, 3>                         (:1031-1037)
+// with the same parameter-block order and sizes, so problem_->AddResidualBlock(cost, loss, qvec, tvec, xyz, params)
+// and everything after it (loss functions, SetManifold / SetParameterBlockConstant, ceres::Solve, the iteration
+// callback of controllers/bundle_adjustment.cc:43-61) stays as it is.  Wiring (controllers keep their code):
+//
+//   BundleAdjusterHip hip(options, config);  hip.SetUp(reconstruction, phrase);  hip.Create(device);
+//   HipEvaluation<Source> cb(&hip, Source(reconstruction));
+//   problem_options.evaluation_callback = &cb;                      // ceres::Problem::Options
+//   for (o : observations)  problem.AddResidualBlock(cb.ReprojectionBlock(o), loss, <blocks as before>);
+//   for (l : lidar terms)   problem.AddResidualBlock(cb.LidarBlock(l), loss, xyz);
+//
+// Ceres calls PrepareForEvaluation(jacobians, new_point) once per evaluation with the parameter memory (owned by
+// Reconstruction, updated in place) holding the evaluation point; Evaluate may then run concurrently from Ceres'
+// threads -- it only reads the result buffers.  jacobians == NULL and jacobians[i] == NULL (constant block) are
+// honoured as Ceres requires.  COLMAP_PCD_HIP=0 (HipBackendEnabled) keeps the reference's own autodiff blocks.
+#pragma once
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#if __has_include(<ceres/ceres.h>)
+#include <ceres/ceres.h>
+#else
+#include "ceres_interface_stub.h"
+#endif
+
+#include "ba_problem.h"
+
+namespace colmap_hip {
+
+// Run-time switch of the whole drop-in (SURVEY section 5 "Config / flags"): COLMAP_PCD_HIP=0 keeps the reference's CPU
+// path (PCL/FLANN KD-tree loops, Ceres autodiff); unset or any other value uses libpcdhip when a gfx950 device exists.
+// The call sites test it once: `if (colmap_hip::HipBackendEnabled()) { batched path } else { original loop }`.
+inline bool HipBackendEnabled() {
+  const char* e = std::getenv("COLMAP_PCD_HIP");
+  if (e && e[0] == '0' && e[1] == '\0') return false;
+  return pcd_device_count() > 0;
+}
+
+// Where the parameter blocks live.  With COLMAP: Qvec = reconstruction->Image(id).Qvec().data(), Tvec likewise,
+// XYZ = reconstruction->Point3D(id).XYZ().data(), Params = reconstruction->Camera(id).ParamsData()
+// (the pointers handed to AddResidualBlock at optim/bundle_adjustment.cc:825-828, :894).
+struct ShimParameterSource {
+  Reconstruction* rec;
+  explicit ShimParameterSource(Reconstruction* r) : rec(r) {}
+  double* Qvec(image_t id) const { return rec->images.at(id).qvec; }
+  double* Tvec(image_t id) const { return rec->images.at(id).tvec; }
+  double* XYZ(point3D_t id) const { return rec->points3D.at(id).xyz; }
+  double* Params(camera_t id) const { return rec->cameras.at(id).params.data(); }
+};
+
+struct HipBlockBuffers {   // results of the last PrepareForEvaluation, read by every block
+  std::vector<double> residuals, jac_q, jac_t, jac_X, jac_lidar, jac_cam;
+  bool have_jacobians = false;
+};
+
+// one reprojection residual block (variable or constant pose), optim/bundle_adjustment.cc:858-893, :967-983
+class HipReprojectionBlock : public ceres::CostFunction {
+ public:
+  HipReprojectionBlock(const HipBlockBuffers* buf, size_t obs, bool constant_pose, int num_camera_params)
+      : buf_(buf), o_(obs), cpose_(constant_pose), K_(num_camera_params) {
+    set_num_residuals(2);
+    if (!cpose_) { mutable_parameter_block_sizes()->push_back(4); mutable_parameter_block_sizes()->push_back(3); }
+    mutable_parameter_block_sizes()->push_back(3);
+    mutable_parameter_block_sizes()->push_back(K_);
+  }
+  bool Evaluate(double const* const*, double* residuals, double** jacobians) const override {
+    residuals[0] = buf_->residuals[2 * o_];
+    residuals[1] = buf_->residuals[2 * o_ + 1];
+    if (!jacobians) return true;
+    if (!buf_->have_jacobians) return false;   // Ceres asked for Jacobians the callback was not told to prepare
+    int b = 0;
+    if (!cpose_) {
+      if (jacobians[b]) std::memcpy(jacobians[b], &buf_->jac_q[8 * o_], 8 * sizeof(double));
+      ++b;
+      if (jacobians[b]) std::memcpy(jacobians[b], &buf_->jac_t[6 * o_], 6 * sizeof(double));
+      ++b;
+    }
+    if (jacobians[b]) std::memcpy(jacobians[b], &buf_->jac_X[6 * o_], 6 * sizeof(double));
+    ++b;
+    if (jacobians[b])
+      for (int r = 0; r < 2; ++r)   // device rows have PCD_CAM_JAC_STRIDE columns, Ceres wants 2 x K row-major
+        std::memcpy(jacobians[b] + r * K_, &buf_->jac_cam[(2 * o_ + r) * PCD_CAM_JAC_STRIDE], K_ * sizeof(double));
+    return true;
+  }
+
+ private:
+  const HipBlockBuffers* buf_;
+  size_t o_;
+  bool cpose_;
+  int K_;
+};
+
+// one point-to-plane residual block, optim/bundle_adjustment.cc:1031-1037
+class HipLidarBlock : public ceres::CostFunction {
+ public:
+  HipLidarBlock(const HipBlockBuffers* buf, size_t num_obs, size_t l) : buf_(buf), O_(num_obs), l_(l) {
+    set_num_residuals(1);
+    mutable_parameter_block_sizes()->push_back(3);
+  }
+  bool Evaluate(double const* const*, double* residuals, double** jacobians) const override {
+    residuals[0] = buf_->residuals[2 * O_ + l_];
+    if (jacobians && jacobians[0]) {
+      if (!buf_->have_jacobians) return false;
+      std::memcpy(jacobians[0], &buf_->jac_lidar[3 * l_], 3 * sizeof(double));
+    }
+    return true;
+  }
+
+ private:
+  const HipBlockBuffers* buf_;
+  size_t O_, l_;
+};
+
+template <typename Source = ShimParameterSource>
+class HipEvaluation : public ceres::EvaluationCallback {
+ public:
+  // `ba` must have been SetUp() and Create()d; `src` gives the parameter memory Ceres optimises in place
+  HipEvaluation(BundleAdjusterHip* ba, const Source& src) : ba_(ba), src_(src) {
+    const size_t O = ba_->obs_image_.size(), L = ba_->lidar_point_.size();
+    buf_.residuals.assign(2 * O + L, 0.0);
+    buf_.jac_q.assign(8 * O, 0.0); buf_.jac_t.assign(6 * O, 0.0); buf_.jac_X.assign(6 * O, 0.0);
+    buf_.jac_lidar.assign(3 * L, 0.0);
+    buf_.jac_cam.assign(2 * (size_t)PCD_CAM_JAC_STRIDE * O, 0.0);
+    for (uint8_t v : ba_->cam_refine_) cameras_variable_ |= v != 0;
+  }
+
+  void PrepareForEvaluation(bool evaluate_jacobians, bool new_evaluation_point) override {
+    ok_ = true;
+    if (new_evaluation_point) {
+      // gather the evaluation point from the solver's parameter blocks (flat order of ba_problem.h)
+      for (size_t i = 0; i < ba_->image_ids_.size(); ++i) {
+        std::memcpy(&ba_->poses_[7 * i], src_.Qvec(ba_->image_ids_[i]), 4 * sizeof(double));
+        std::memcpy(&ba_->poses_[7 * i + 4], src_.Tvec(ba_->image_ids_[i]), 3 * sizeof(double));
+      }
+      for (size_t p = 0; p < ba_->point_ids_.size(); ++p)
+        std::memcpy(&ba_->points_[3 * p], src_.XYZ(ba_->point_ids_[p]), 3 * sizeof(double));
+      ok_ &= pcd_ba_set_parameters(ba_->handle(), ba_->poses_.data(), ba_->points_.data()) == PCD_OK;
+      if (cameras_variable_) {
+        for (size_t c = 0; c < ba_->camera_ids_.size(); ++c)
+          std::memcpy(&ba_->cam_params_[ba_->cam_off_[c]], src_.Params(ba_->camera_ids_[c]),
+                      pcd_camera_num_params(ba_->cam_model_[c]) * sizeof(double));
+        ok_ &= pcd_ba_set_camera_parameters(ba_->handle(), ba_->cam_params_.data()) == PCD_OK;
+      }
+    }
+    pcd_ba_out o{};
+    o.residuals = buf_.residuals.data();
+    if (evaluate_jacobians) {
+      o.jac_q = buf_.jac_q.data(); o.jac_t = buf_.jac_t.data(); o.jac_X = buf_.jac_X.data();
+      o.jac_lidar = buf_.jac_lidar.data();
+      if (cameras_variable_) o.jac_cam = buf_.jac_cam.data();   // constant cameras: Ceres passes NULL for that block
+    }
+    ok_ &= pcd_ba_evaluate(ba_->handle(), &o) == PCD_OK;        // ONE batch for every residual block
+    buf_.have_jacobians = evaluate_jacobians && ok_;
+    ++num_evaluations_;
+  }
+
+  // blocks in the order of ba_problem.h's flat arrays (= the order of the reference's AddResidualBlock calls);
+  // ownership passes to the caller (Ceres takes it in AddResidualBlock)
+  ceres::CostFunction* ReprojectionBlock(size_t o) const {
+    const int im = ba_->obs_image_[o];
+    return new HipReprojectionBlock(&buf_, o, ba_->image_const_pose_[im] != 0,
+                                    pcd_camera_num_params(ba_->cam_model_[ba_->image_cam_[im]]));
+  }
+  ceres::CostFunction* LidarBlock(size_t l) const { return new HipLidarBlock(&buf_, ba_->obs_image_.size(), l); }
+
+  bool ok() const { return ok_; }
+  size_t num_evaluations() const { return num_evaluations_; }
+  const HipBlockBuffers& buffers() const { return buf_; }
+
+ private:
+  BundleAdjusterHip* ba_;
+  Source src_;
+  HipBlockBuffers buf_;
+  bool cameras_variable_ = false, ok_ = true;
+  size_t num_evaluations_ = 0;
+};
+
+}  // namespace colmap_hip

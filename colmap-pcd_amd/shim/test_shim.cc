@@ -11,6 +11,7 @@
 #include <random>
 
 #include "ba_problem.h"
+#include "ceres_adapter.h"
 #include "pose_reader.h"
 #include "sift_match_hip.h"
 #include "lidar_hip.h"
@@ -450,6 +451,177 @@ static int TestGpuProjection() {
   return 0;
 }
 
+
+// ---- Ceres adapter (shim/ceres_adapter.h) -----------------------------------------------------------------------
+// block shapes = the template arguments of the reference's AutoDiffCostFunction instantiations
+// (optim/bundle_adjustment.cc:858-893, :967-983, :1031-1037); no GPU needed
+static void TestCeresBlockShapes() {
+  HipBlockBuffers buf;
+  buf.residuals = {1, 2, 3, 4, 5};
+  HipReprojectionBlock var(&buf, 0, false, 4), cst(&buf, 1, true, 8);
+  HipLidarBlock lid(&buf, 2, 0);
+  CHECK_EQ(var.num_residuals(), 2); CHECK_EQ(cst.num_residuals(), 2); CHECK_EQ(lid.num_residuals(), 1);
+  CHECK((var.parameter_block_sizes() == std::vector<int32_t>{4, 3, 3, 4}));
+  CHECK((cst.parameter_block_sizes() == std::vector<int32_t>{3, 8}));
+  CHECK((lid.parameter_block_sizes() == std::vector<int32_t>{3}));
+  double r[2] = {0, 0};
+  CHECK(var.Evaluate(nullptr, r, nullptr) && r[0] == 1 && r[1] == 2);   // residual-only evaluation
+  CHECK(cst.Evaluate(nullptr, r, nullptr) && r[0] == 3 && r[1] == 4);
+  CHECK(lid.Evaluate(nullptr, r, nullptr) && r[0] == 5);
+  double j[8]; double* jac[4] = {j, nullptr, nullptr, nullptr};
+  CHECK(!var.Evaluate(nullptr, r, jac));   // Jacobians requested but the callback prepared none
+}
+
+// End-to-end replay of the reference's batch call order (controllers/bundle_adjustment.cc:76-204):
+// PLY -> PointCloudProcess::Initialize -> association of EVERY 3D point (batched, controller gate) ->
+// AddVariablePoint / AddLidarPoint -> BundleAdjuster SetUp (WholeMap) -> what ceres::Solve does per iteration:
+// EvaluationCallback::PrepareForEvaluation, then CostFunction::Evaluate of every residual block.
+static int TestGpuCeresAdapterEndToEnd() {
+  // LiDAR map: floor y = 0.5 (visual frame) on a 5 cm lattice, normals (0,1,0), written as a binary PLY
+  std::vector<float> xyz, nrm;
+  for (int i = -60; i <= 60; ++i)
+    for (int j = -60; j <= 60; ++j) {
+      const float vx = 0.05f * i, vy = 0.5f, vz = 0.05f * j;
+      xyz.insert(xyz.end(), {vz, -vx, -vy});                           // raw LiDAR frame = (z', -x', -y')
+      nrm.insert(nrm.end(), {0.f, 0.f, -1.f});
+    }
+  const std::string ply = WritePly(true, false, xyz, nrm);
+  lidar::PointCloudProcess pcp(ply);
+  CHECK(pcp.Initialize());                                             // :124 LoadPointcloud
+  std::remove(ply.c_str());
+  Reconstruction rec;
+  GenerateReconstruction(3, 80, &rec);
+  rec.cameras[2].params[3] = 0.01;                                     // some distortion on one camera
+  BundleAdjustmentConfig config;
+  for (image_t i = 0; i < 3; ++i) config.AddImage(i);                  // :109
+  config.SetConstantPose(0);
+  config.SetConstantTvec(1, {0});
+  // :130-185, batched: every point3D is a variable point; associated ones get a LidarPoint
+  std::vector<uint64_t> ids; std::vector<double> pts;
+  for (point3D_t p = 1; p <= 80; ++p) {
+    config.AddVariablePoint(p);
+    ids.push_back(p);
+    pts.insert(pts.end(), rec.points3D[p].xyz, rec.points3D[p].xyz + 3);
+  }
+  std::unordered_map<uint64_t, LidarPoint> maps;
+  CHECK(MatchClosestLidarPoints(pcp, ids, pts, {0.0}, PCD_GATE_CONTROLLER, &maps));
+  size_t expect = 0;
+  for (point3D_t p = 1; p <= 80; ++p) expect += std::fabs(rec.points3D[p].xyz[1] - 0.5) <= 1.0;   // dist2plane gate
+  CHECK_EQ(maps.size(), expect);
+  CHECK(expect > 40 && expect < 80);
+  for (const auto& kv : maps) {
+    CHECK(kv.second.type == LidarPointType::IcpGround);                // |ny/nx| = inf > 10
+    config.AddLidarPoint(kv.first, kv.second);                         // :179
+  }
+  BundleAdjustmentOptions options = UpstreamOptions();                 // refined f + k: camera blocks are live
+  options.loss_function_type = PCD_LOSS_SOFT_L1;                       // Ceres applies the loss itself: raw blocks
+  BundleAdjusterHip ba(options, config);
+  ba.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::WholeMap);         // :198 SetOptimazePhrase(WholeMap), :479
+  CHECK_EQ(ba.NumResiduals(), 2u * 240u + expect);
+  CHECK(ba.Create(0));
+  ShimParameterSource src(&rec);
+  HipEvaluation<> cb(&ba, src);
+  // the residual blocks exactly as AddResidualBlock receives them
+  struct Block { std::unique_ptr<ceres::CostFunction> f; std::vector<double*> params; std::vector<bool> constant; };
+  std::vector<Block> blocks;
+  for (size_t o = 0; o < ba.obs_image_.size(); ++o) {
+    const int im = ba.obs_image_[o], pt = ba.obs_point_[o], cm = ba.image_cam_[im];
+    Block b;
+    b.f.reset(cb.ReprojectionBlock(o));
+    if (!ba.image_const_pose_[im]) {
+      b.params = {src.Qvec(ba.image_ids_[im]), src.Tvec(ba.image_ids_[im])};
+      b.constant = {false, false};
+    }
+    b.params.push_back(src.XYZ(ba.point_ids_[pt])); b.constant.push_back(ba.point_const_[pt] != 0);
+    b.params.push_back(src.Params(ba.camera_ids_[cm])); b.constant.push_back(!ba.CameraVariable(cm));
+    CHECK_EQ(b.f->parameter_block_sizes().size(), b.params.size());
+    blocks.push_back(std::move(b));
+  }
+  for (size_t l = 0; l < ba.lidar_point_.size(); ++l) {
+    Block b;
+    b.f.reset(cb.LidarBlock(l));
+    b.params = {src.XYZ(ba.point_ids_[ba.lidar_point_[l]])};
+    b.constant = {false};
+    blocks.push_back(std::move(b));
+  }
+  // reference values: one direct evaluation through the C ABI
+  const size_t O = ba.obs_image_.size(), L = ba.lidar_point_.size();
+  std::vector<double> res(2 * O + L), jq(8 * O), jt(6 * O), jx(6 * O), jl(3 * L), jc(2 * PCD_CAM_JAC_STRIDE * O);
+  pcd_ba_out direct{};
+  direct.residuals = res.data(); direct.jac_q = jq.data(); direct.jac_t = jt.data(); direct.jac_X = jx.data();
+  direct.jac_lidar = jl.data(); direct.jac_cam = jc.data();
+  CHECK_EQ((int)pcd_ba_evaluate(ba.handle(), &direct), (int)PCD_OK);
+  auto evaluate_all = [&](bool with_jac, std::vector<double>* all_r, std::vector<std::vector<double>>* all_j) {
+    all_r->clear(); all_j->clear();
+    bool ok = true;
+    for (Block& b : blocks) {
+      double r[2] = {0, 0};
+      std::vector<std::vector<double>> j(b.params.size());
+      std::vector<double*> jp(b.params.size(), nullptr);
+      for (size_t k = 0; k < b.params.size(); ++k) {
+        j[k].assign((size_t)b.f->num_residuals() * b.f->parameter_block_sizes()[k], -777.0);
+        if (!b.constant[k]) jp[k] = j[k].data();                       // Ceres passes NULL for constant blocks
+      }
+      ok &= b.f->Evaluate(b.params.data(), r, with_jac ? jp.data() : nullptr);
+      for (int k = 0; k < b.f->num_residuals(); ++k) all_r->push_back(r[k]);
+      for (auto& v : j) all_j->push_back(v);
+    }
+    return ok;
+  };
+  std::vector<double> r1; std::vector<std::vector<double>> j1;
+  cb.PrepareForEvaluation(/*evaluate_jacobians=*/true, /*new_evaluation_point=*/true);
+  CHECK(cb.ok());
+  CHECK(evaluate_all(true, &r1, &j1));
+  CHECK(r1 == res);                                                    // every residual, bit for bit
+  size_t jb = 0, checked = 0, untouched = 0;
+  for (size_t o = 0; o < O; ++o) {
+    const int im = ba.obs_image_[o], cm = ba.image_cam_[im], K = pcd_camera_num_params(ba.cam_model_[cm]);
+    if (!ba.image_const_pose_[im]) {
+      CHECK(std::equal(j1[jb].begin(), j1[jb].end(), jq.begin() + 8 * o)); ++jb;
+      CHECK(std::equal(j1[jb].begin(), j1[jb].end(), jt.begin() + 6 * o)); ++jb;
+      checked += 2;
+    }
+    CHECK(std::equal(j1[jb].begin(), j1[jb].end(), jx.begin() + 6 * o)); ++jb;
+    if (ba.CameraVariable(cm)) {
+      for (int row = 0; row < 2; ++row)
+        CHECK(std::equal(j1[jb].begin() + row * K, j1[jb].begin() + (row + 1) * K, jc.begin() + (2 * o + row) * PCD_CAM_JAC_STRIDE));
+      ++checked;
+    } else {
+      CHECK(j1[jb][0] == -777.0); ++untouched;                         // NULL Jacobian pointer: nothing written
+    }
+    ++jb;
+  }
+  for (size_t l = 0; l < L; ++l) { CHECK(std::equal(j1[jb].begin(), j1[jb].end(), jl.begin() + 3 * l)); ++jb; }
+  CHECK_EQ(jb, j1.size());
+  CHECK(checked > O && untouched == 0);
+  // residual-only evaluation (LM trial step): Evaluate(params, r, NULL)
+  std::vector<double> r2; std::vector<std::vector<double>> j2;
+  cb.PrepareForEvaluation(false, false);
+  CHECK(evaluate_all(false, &r2, &j2) && r2 == res);
+  CHECK(!evaluate_all(true, &r2, &j2));                                // Jacobians were not prepared: blocks say so
+  // the solver moves the parameters IN PLACE (Reconstruction memory); the next evaluation must see them
+  rec.images[2].tvec[0] += 0.05; rec.points3D[7].xyz[2] -= 0.02; rec.cameras[1].params[0] *= 1.001;
+  cb.PrepareForEvaluation(true, true);
+  std::vector<double> r3; std::vector<std::vector<double>> j3;
+  CHECK(evaluate_all(true, &r3, &j3) && r3 != res);
+  BundleAdjusterHip fresh(options, config);                            // same problem assembled from the moved state
+  fresh.SetUp(&rec, BundleAdjusterHip::OptimazePhrase::WholeMap);
+  CHECK(fresh.Create(0));
+  std::vector<double> res_fresh(2 * O + L);
+  pcd_ba_out of{}; of.residuals = res_fresh.data();
+  CHECK_EQ((int)pcd_ba_evaluate(fresh.handle(), &of), (int)PCD_OK);
+  CHECK(r3 == res_fresh);
+  CHECK_EQ(cb.num_evaluations(), 3u);
+  // run-time switch
+  setenv("COLMAP_PCD_HIP", "0", 1);
+  CHECK(!HipBackendEnabled());
+  setenv("COLMAP_PCD_HIP", "1", 1);
+  CHECK(HipBackendEnabled());
+  unsetenv("COLMAP_PCD_HIP");
+  CHECK(HipBackendEnabled());
+  return 0;
+}
+
 static int TestGpu() {
   if (pcd_device_count() < 1) { std::printf("FAIL: --gpu given but no gfx950 device\n"); return 1; }
   // cloud: plane y = 1 (visual frame) on a 5 cm lattice with normal (0,1,0), given in the raw LiDAR frame
@@ -516,7 +688,7 @@ static int TestGpu() {
   for (double r : res) s += r * r;
   CHECK(std::fabs(cost - 0.5 * s) <= 1e-9 * cost);
   CHECK(cost > 0 && cost < 300 * 8.0 + 1e4);   // +-2 px noise on 300 observations + one lidar term
-  return TestGpuProjection() + TestGpuSiftMatcher();
+  return TestGpuProjection() + TestGpuSiftMatcher() + TestGpuCeresAdapterEndToEnd();
 }
 
 int main(int argc, char** argv) {
@@ -532,6 +704,7 @@ int main(int argc, char** argv) {
   TestPlyReader();
   TestPoseReader();
   TestMatchVariablePoint();
+  TestCeresBlockShapes();
   if (argc > 1 && std::strcmp(argv[1], "--gpu") == 0) g_fail += TestGpu();
   std::printf(g_fail ? "%d FAILED\n" : "ALL OK\n", g_fail);
   return g_fail ? 1 : 0;

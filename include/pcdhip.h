@@ -88,6 +88,9 @@ typedef struct {
   uint64_t num_indexed;      /* finite points in the grid (Inf rows keep an index, never win) */
   uint64_t occupied_cells;
   double build_ms;
+  float bbox_lo[3], bbox_hi[3];   /* tight bounds of the finite rows (meaningful when num_indexed > 0): what    */
+                                  /* pcd_nn_refine_device tests queries against, and what a caller uses to send */
+                                  /* each query to its home shard                                               */
 } pcd_cloud_info;
 pcd_status pcd_cloud_get_info(const pcd_cloud* c, pcd_cloud_info* info);
 
@@ -122,6 +125,16 @@ pcd_status pcd_nn_query_algo(pcd_cloud* c, const double* q_xyz, uint64_t Q, int 
 #define PCD_KEY_NONE 0x7FFFFFFFFFFFFFFFull
 pcd_status pcd_nn_query_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q, int algo,
                                uint64_t* d_keys, void* stream);
+
+/* Second phase of a search over SHARDS of one cloud (spatially compact shards, one per GPU).
+ * d_keys comes in holding the best key found so far for every query (from the query's home shard after a
+ * cross-rank MIN; PCD_KEY_NONE = nothing yet) and leaves holding min(incoming, this shard's result).  A query is
+ * searched here only if it can still improve: not d_skip[i] (may be NULL; e.g. queries whose home is this shard)
+ * and the exact float lower bound of its distance to the shard's bounding box does not exceed its incoming
+ * distance (an equal distance is searched: a lower index may hide here).  All other entries are left untouched.
+ * The element-wise MIN over ranks of the outputs is the exact single-cloud result, ties included. */
+pcd_status pcd_nn_refine_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q, const uint8_t* d_skip,
+                                uint64_t* d_keys, void* stream);
 
 /* ------------------------------------------------------------------------
  * Plane association                          replaces the three serial loops
@@ -313,6 +326,8 @@ void pcd_ba_destroy(pcd_ba* ba);
 
 /* parameter update between iterations (host -> device); NULL keeps the old values */
 pcd_status pcd_ba_set_parameters(pcd_ba* ba, const double* poses /*[I][7]*/, const double* points /*[P][3]*/);
+/* refined intrinsics: the camera parameter blocks change between iterations too (same layout as desc.cam_params) */
+pcd_status pcd_ba_set_camera_parameters(pcd_ba* ba, const double* cam_params /*[cam_params_len]*/);
 
 /* Outputs of one evaluation; every pointer may be NULL (not computed / not copied).
  * Raw blocks are exactly what each CostFunction::Evaluate hands to Ceres
