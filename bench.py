@@ -244,6 +244,53 @@ def main():
         t_ba = timed(ba_step, a.steps, sync)
         extras.update(ba_raw_iter_ms=t_raw * 1e3, nn_wall_ms=t_nn * 1e3, ba_wall_ms=t_ba * 1e3)
         del raw, res_only
+        # ---- the drop-in's host path: pinned staging -> H2D -> search + epilogue -> compaction -> D2H of the hits ----
+        # (what shim/lidar_hip.h MatchClosestLidarPointsFlat costs after the call site has gathered XYZ into the
+        #  staging buffers and before it inserts into its hash maps; both exist in the reference's loops as well)
+        sq, smr = cloud.staging(Q)
+        sq[:] = q
+        smr[:] = mr
+        for _ in range(2):
+            hits = cloud.associate_staged(Q, Q, pcdhip.GATE_MAPPER_LOCAL)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            hits = cloud.associate_staged(Q, Q, pcdhip.GATE_MAPPER_LOCAL)
+        t_e2e = (time.perf_counter() - t0) / a.steps
+        extras.update(e2e_ms=t_e2e * 1e3, e2e_hits=int(len(hits)),
+                      e2e_def="pcd_associate_staged: pinned inputs -> pinned 80-B records of the accepted associations, "
+                              "PCIe both ways included", e2e_over_device=t_e2e / t_nn)
+        # ---- config A (Smith Hall 25-like): 2 M-point cloud, 20 k queries per call -> latency per call ----
+        if rank == 0:
+            xa, na = synth.cloud_planes(2_000_000)
+            ca = pcdhip.Cloud(xa, na, device=local_rank, raw_lidar_frame=False)
+            qa = torch.from_numpy(synth.queries(xa, 20_000, seed=3)).to(dev)
+            mra = torch.from_numpy(synth.max_range_schedule(20_000, seed=3)).to(dev)
+            ka = torch.empty(20_000, dtype=torch.int64, device=dev)
+            oa = {k: v[:20_000] for k, v in aout.items()} if Q >= 20_000 else None
+            if oa is not None:
+                def a_step():
+                    ca.nn_device(qa, 20_000, ka, pcdhip.NN_AUTO, stream)
+                    ca.associate_device(qa, 20_000, mra, 20_000, pcdhip.GATE_MAPPER_LOCAL, oa, ka, stream)
+                for _ in range(3):
+                    a_step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    a_step()
+                torch.cuda.synchronize()
+                t_a = (time.perf_counter() - t0) / 50
+                sqa, smra = ca.staging(20_000)
+                sqa[:] = qa.cpu().numpy(); smra[:] = mra.cpu().numpy()
+                ca.associate_staged(20_000, 20_000, pcdhip.GATE_MAPPER_LOCAL)
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    ca.associate_staged(20_000, 20_000, pcdhip.GATE_MAPPER_LOCAL)
+                t_a2 = (time.perf_counter() - t0) / 50
+                extras["config_A"] = dict(workload="2M-pt cloud / 20k queries per call (incremental mapper's local BA, "
+                                                   "sfm/incremental_mapper.cc:1155-1165)",
+                                          device_us_per_call=t_a * 1e6, e2e_us_per_call=t_a2 * 1e6,
+                                          queries_per_sec=20_000 / t_a)
+            ca.close()
 
     # ------------------------------------------------- cloud-sharded NN (north_star's collective) ---
     cs = None

@@ -9,6 +9,10 @@
 //   sfm/incremental_mapper.cc:1444-1463  same gate, dist/angle not stored by the reference      (mode 1)
 //   controllers/bundle_adjustment.cc:156-176 gate dist2plane > 1 || dist2point > 2              (mode 2)
 // Compiled with -ffp-contract=off so the operation order below is what runs.
+#include <cstring>  // rocprim's texture_cache_iterator.hpp needs memset declared first
+
+#include <rocprim/rocprim.hpp>
+
 #include "cloud.h"
 #include "scratch.h"
 
@@ -149,6 +153,29 @@ __global__ void k_filter_lidar_outlier(const double* __restrict__ X, const doubl
   erase[i] = e;
 }
 
+// accepted associations (type != 0) -> 80-byte records at their scanned position, ascending query order
+struct HitFlag {
+  const uint8_t* type;
+  __device__ uint32_t operator()(uint32_t i) const { return type[i] != PCD_LIDAR_NONE ? 1u : 0u; }
+};
+__global__ void k_pack_hits(const uint8_t* __restrict__ type, const uint32_t* __restrict__ pos, uint32_t Q,
+                            const double* __restrict__ xyz, const double* __restrict__ abcd,
+                            const double* __restrict__ dist, const double* __restrict__ angle,
+                            pcd_assoc_hit* __restrict__ hits, uint32_t* __restrict__ count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  const uint8_t t = type[i];
+  if (t != PCD_LIDAR_NONE) {
+    pcd_assoc_hit h;
+    for (int k = 0; k < 3; ++k) h.lidar_xyz[k] = xyz[3 * (size_t)i + k];
+    for (int k = 0; k < 4; ++k) h.abcd[k] = abcd[4 * (size_t)i + k];
+    h.dist = dist[i]; h.angle = angle[i];
+    h.query = i; h.type = t; h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    hits[pos[i]] = h;
+  }
+  if (i == Q - 1) *count = pos[i] + (t != PCD_LIDAR_NONE ? 1u : 0u);
+}
+
 pcd_status nn_query_device_internal(pcd_cloud* c, const double* d_q, uint64_t Q, int algo, uint64_t* d_keys,
                                     hipStream_t s);
 
@@ -233,6 +260,66 @@ pcd_status pcd_filter_lidar_outlier_device(int device, const double* d_points_xy
   hipLaunchKernelGGL(k_filter_lidar_outlier, dim3(div_up(n, 256)), dim3(256), 0, s, d_points_xyz, d_lidar_xyz, d_type,
                      n, max_proj_dist_error, max_icp_dist_error, d_erase);
   PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
+
+pcd_status pcd_assoc_staging(pcd_cloud* c, uint64_t Q, double** q_xyz, double** max_range) {
+  PCD_REQUIRE(c && q_xyz && max_range, "null pointer");
+  PCD_HIP_TRY(hipSetDevice(c->device));
+  QueryScratch& a = *scratch_of(c);
+  PCD_TRY(a.h_q.reserve(3 * std::max<uint64_t>(Q, 1)));
+  PCD_TRY(a.h_mr.reserve(std::max<uint64_t>(Q, 1)));
+  *q_xyz = a.h_q.p;
+  *max_range = a.h_mr.p;
+  return PCD_OK;
+}
+
+pcd_status pcd_associate_staged(pcd_cloud* c, uint64_t Q, uint64_t max_range_count, int gate_mode,
+                                const pcd_assoc_hit** hits, uint64_t* num_hits) {
+  PCD_REQUIRE(c && hits && num_hits, "null pointer");
+  PCD_REQUIRE(gate_mode >= 0 && gate_mode <= 2, "gate_mode");
+  PCD_REQUIRE(gate_mode == PCD_GATE_CONTROLLER || max_range_count == 1 || max_range_count == Q,
+              "max_range must have 1 or Q entries");
+  *hits = nullptr;
+  *num_hits = 0;
+  if (Q == 0) return PCD_OK;
+  PCD_REQUIRE(Q < 0xFFFFFFF0ull, "more than 2^32 queries in one call");
+  PCD_HIP_TRY(hipSetDevice(c->device));
+  QueryScratch& a = *scratch_of(c);
+  PCD_REQUIRE(a.h_q.n >= 3 * Q && a.h_mr.n >= std::max<uint64_t>(max_range_count, 1),
+              "call pcd_assoc_staging(Q) and fill the buffers first");
+  hipStream_t s = nullptr;
+  PCD_TRY(a.d_q.reserve(3 * Q));
+  PCD_TRY(a.a_mr.reserve(std::max<uint64_t>(max_range_count, 1)));
+  PCD_TRY(a.a_xyz.reserve(3 * Q)); PCD_TRY(a.a_abcd.reserve(4 * Q)); PCD_TRY(a.a_dist.reserve(Q));
+  PCD_TRY(a.a_angle.reserve(Q)); PCD_TRY(a.a_type.reserve(Q));
+  PCD_TRY(a.hit_pos.reserve(Q)); PCD_TRY(a.d_hits.reserve(Q)); PCD_TRY(a.h_hits.reserve(Q)); PCD_TRY(a.h_count.reserve(1));
+  PCD_TRY(a.hit_count.reserve(1));
+  PCD_HIP_TRY(hipMemcpyAsync(a.d_q.p, a.h_q.p, 3 * Q * sizeof(double), hipMemcpyHostToDevice, s));
+  if (gate_mode != PCD_GATE_CONTROLLER)
+    PCD_HIP_TRY(hipMemcpyAsync(a.a_mr.p, a.h_mr.p, max_range_count * sizeof(double), hipMemcpyHostToDevice, s));
+  pcd_assoc_out d{a.a_xyz.p, a.a_abcd.p, a.a_type.p, a.a_dist.p, a.a_angle.p, nullptr, nullptr, nullptr};
+  PCD_TRY(pcd_associate_device(c, a.d_q.p, Q, a.a_mr.p, max_range_count, gate_mode, nullptr, &d, s));
+  {
+    ScopedKernelTimer t("associate_compact", s);
+    const auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), HitFlag{a.a_type.p});
+    size_t tb = 0;
+    PCD_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, flags, a.hit_pos.p, 0u, (size_t)Q, rocprim::plus<uint32_t>(), s));
+    PCD_TRY(a.tmp.reserve(tb));
+    PCD_HIP_TRY(rocprim::exclusive_scan(a.tmp.p, tb, flags, a.hit_pos.p, 0u, (size_t)Q, rocprim::plus<uint32_t>(), s));
+    uint32_t* d_count = a.hit_count.p;
+    hipLaunchKernelGGL(k_pack_hits, dim3(div_up(Q, 256)), dim3(256), 0, s, a.a_type.p, a.hit_pos.p, (uint32_t)Q,
+                       a.a_xyz.p, a.a_abcd.p, a.a_dist.p, a.a_angle.p, a.d_hits.p, d_count);
+    PCD_HIP_TRY(hipMemcpyAsync(a.h_count.p, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  }
+  PCD_HIP_TRY(hipStreamSynchronize(s));
+  const uint32_t m = a.h_count.p[0];
+  if (m) {
+    PCD_HIP_TRY(hipMemcpyAsync(a.h_hits.p, a.d_hits.p, (size_t)m * sizeof(pcd_assoc_hit), hipMemcpyDeviceToHost, s));
+    PCD_HIP_TRY(hipStreamSynchronize(s));
+  }
+  *hits = a.h_hits.p;
+  *num_hits = m;
   return PCD_OK;
 }
 

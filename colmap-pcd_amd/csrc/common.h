@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -68,6 +69,35 @@ struct DevBuf {
     if (e != hipSuccess) {
       p = nullptr;
       set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+      return PCD_ERR_OOM;
+    }
+    n = count;
+    return PCD_OK;
+  }
+};
+
+// pinned host buffer (hipHostMalloc), grow-only
+template <typename T>
+struct PinnedBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { release(); }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  pcd_status reserve(size_t count) {
+    if (count <= n) return PCD_OK;
+    release();
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      p = nullptr;
+      set_error("hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
       return PCD_ERR_OOM;
     }
     n = count;

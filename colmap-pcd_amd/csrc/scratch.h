@@ -26,6 +26,12 @@ struct QueryScratch {
   DevBuf<double> a_mr, a_xyz, a_abcd, a_dist, a_angle, a_d2p;
   DevBuf<uint8_t> a_type;
   DevBuf<uint64_t> a_keys;
+  // staged host path (pcd_assoc_staging / pcd_associate_staged): pinned inputs / results, compaction scratch
+  PinnedBuf<double> h_q, h_mr;
+  PinnedBuf<pcd_assoc_hit> h_hits;
+  PinnedBuf<uint32_t> h_count;
+  DevBuf<pcd_assoc_hit> d_hits;
+  DevBuf<uint32_t> hit_pos, hit_count;
 };
 
 inline QueryScratch* scratch_of(pcd_cloud* c) {

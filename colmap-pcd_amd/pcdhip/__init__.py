@@ -50,6 +50,16 @@ class AssocOut(C.Structure):
                 ("nn_sqdist", C.c_void_p)]
 
 
+class AssocHit(C.Structure):
+    _fields_ = [("lidar_xyz", C.c_double * 3), ("abcd", C.c_double * 4), ("dist", C.c_double), ("angle", C.c_double),
+                ("query", C.c_uint32), ("type", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
+HIT_DTYPE = np.dtype([("lidar_xyz", np.float64, 3), ("abcd", np.float64, 4), ("dist", np.float64), ("angle", np.float64),
+                      ("query", np.uint32), ("type", np.uint8), ("pad", np.uint8, 3)])
+assert HIT_DTYPE.itemsize == 80 and C.sizeof(AssocHit) == 80
+
+
 class BADesc(C.Structure):
     _fields_ = [("device", C.c_int32), ("num_cameras", C.c_int32), ("cam_model", C.c_void_p),
                 ("cam_param_offset", C.c_void_p), ("cam_params", C.c_void_p), ("cam_params_len", C.c_uint64),
@@ -88,7 +98,7 @@ ABI_SYMBOLS = [
     "pcd_cloud_options_default", "pcd_cloud_create", "pcd_cloud_destroy", "pcd_cloud_size",
     "pcd_cloud_get_info", "pcd_cloud_download",
     "pcd_nn_query", "pcd_nn_query_algo", "pcd_nn_query_device", "pcd_nn_refine_device",
-    "pcd_associate", "pcd_associate_device", "pcd_nn_winner_payload_device",
+    "pcd_associate", "pcd_associate_device", "pcd_assoc_staging", "pcd_associate_staged", "pcd_nn_winner_payload_device",
     "pcd_associate_from_payload_device", "pcd_search_range_schedule",
     "pcd_camera_num_params", "pcd_camera_param_groups", "pcd_ba_create", "pcd_ba_destroy", "pcd_ba_set_parameters", "pcd_ba_set_camera_parameters",
     "pcd_ba_evaluate", "pcd_ba_evaluate_device", "pcd_ba_device_parameters",
@@ -281,6 +291,29 @@ class Cloud:
             mrc = mr.shape[0]
         _check(lib().pcd_associate(self._h, _vp(q), Q, _vp(mr), mrc, gate_mode, C.byref(ao)))
         return out
+
+    def staging(self, Q):
+        """pinned input buffers of the staged host path: (q_xyz [Q][3], max_range [Q]) numpy views"""
+        L = lib()
+        L.pcd_assoc_staging.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(L.pcd_assoc_staging(self._h, Q, C.byref(a), C.byref(b)))
+        q = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_double)), shape=(max(Q, 1), 3))[:Q]
+        mr = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_double)), shape=(max(Q, 1),))[:Q]
+        return q, mr
+
+    def associate_staged(self, Q, mr_count, gate_mode=GATE_MAPPER_LOCAL):
+        """runs on the buffers of staging(); returns the accepted associations as a structured numpy view (80-byte
+        records, ascending query) of the handle's pinned result buffer -- valid until the next call"""
+        L = lib()
+        L.pcd_associate_staged.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_uint64)]
+        h, n = C.c_void_p(), C.c_uint64(0)
+        _check(L.pcd_associate_staged(self._h, Q, mr_count, gate_mode, C.byref(h), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, HIT_DTYPE)
+        buf = (C.c_char * (80 * n.value)).from_address(h.value)
+        return np.frombuffer(buf, dtype=HIT_DTYPE, count=n.value)
 
     def associate_device(self, d_q, Q, d_max_range, mr_count, gate_mode, d_out, d_keys_in=None, stream=0):
         ao = AssocOut(*[_ptr(d_out.get(k)) for k in ("lidar_xyz", "abcd", "type", "dist", "angle", "dist2plane",

@@ -116,10 +116,10 @@ def bench_cloud_sharded(xyz, nrm, q_all, mr_all, rank, world, local_rank, dev, s
     shard = pcdhip.Cloud(xyz[rows], nrm[rows], device=local_rank, raw_lidar_frame=False, index_base=cuts[rank],
                          index_stride=1)
     info = shard.info()
-    box = torch.tensor([info["bbox_lo"] + info["bbox_hi"]], dtype=torch.float64)
+    box = torch.tensor([info["bbox_lo"] + info["bbox_hi"]], dtype=torch.float64, device=dev)   # device tensors: RCCL
     boxes = [torch.zeros_like(box) for _ in range(world)]
     dist.all_gather(boxes, box)
-    boxes = torch.cat(boxes).numpy()
+    boxes = torch.cat(boxes).cpu().numpy()
     Q = q_all.shape[0]
     home = home_shards(q_all, boxes[:, :3], boxes[:, 3:])
     mine = np.nonzero(home == rank)[0]

@@ -164,6 +164,10 @@ def ba_scene(num_cams, num_points, seed=11, mean_extra=4.0, lidar_frac=0.9, cons
     ok = Pc[:, 2] > 0.5
     obs_image, obs_point, Pc = obs_image[ok], obs_point[ok], Pc[ok]
     x, y = _opencv_project(OPENCV_PARAMS, Pc[:, 0] / Pc[:, 2], Pc[:, 1] / Pc[:, 2])
+    # keep what a 4032 x 3024 image (plus a generous margin) can see: far off-axis rays leave the range in which the
+    # distortion polynomial means anything and would dominate every norm in the tests
+    vis = (np.abs(x - OPENCV_PARAMS[2]) < 4032.0) & (np.abs(y - OPENCV_PARAMS[3]) < 3024.0)
+    obs_image, obs_point, x, y = obs_image[vis], obs_point[vis], x[vis], y[vis]
     obs_xy = np.stack([x, y], axis=1) + rng.uniform(-2, 2, (len(x), 2))
     if order == "image":
         perm = np.argsort(obs_image, kind="stable")

@@ -152,31 +152,54 @@ class PointCloudProcess {
 //   PCD_GATE_CONTROLLER     BundleAdjustmentController::Run                (colour blue 0,0,255)
 // ground points are yellow (255,255,0) at all three.  Returns point3D_id -> LidarPoint for the points the
 // reference would have passed to AddLidarPoint (rejected / not found points are absent).
+// Flat form for the patched loops: the caller gathers Point3D::XYZ() (and the range schedule) straight into the
+// handle's pinned staging buffers through `fill(i, xyz3, &range)`, one H2D / search / epilogue / device-side
+// compaction / D2H round trip follows, and the accepted associations come back as a contiguous array of 80-byte
+// records (ascending i) in pinned memory valid until the next call on this cloud.  The unordered_map inserts of
+// AddLidarPoint stay at the call site:
+//   for (k < n_hits) { const pcd_assoc_hit& h = hits[k]; config.AddLidarPoint(ids[h.query], ToLidarPoint(h, gate)); }
+template <typename Fill>
+inline bool MatchClosestLidarPointsFlat(lidar::PointCloudProcess& pcp, uint64_t n, bool per_point_range, int gate_mode,
+                                        Fill fill, const pcd_assoc_hit** hits, uint64_t* n_hits) {
+  double *q = nullptr, *mr = nullptr;
+  if (!pcp.handle() || pcd_assoc_staging(pcp.handle(), n, &q, &mr) != PCD_OK) return false;
+  double r0 = 0.0;
+  for (uint64_t i = 0; i < n; ++i) fill(i, q + 3 * i, per_point_range ? mr + i : &r0);
+  if (!per_point_range) mr[0] = r0;
+  return pcd_associate_staged(pcp.handle(), n, per_point_range ? n : 1, gate_mode, hits, n_hits) == PCD_OK;
+}
+
+// LidarPoint of one record, with the colour the call site of `gate_mode` paints it
+inline LidarPoint ToLidarPoint(const pcd_assoc_hit& h, int gate_mode) {
+  LidarPoint lp;
+  lp.type = h.type == PCD_LIDAR_ICP_GROUND ? LidarPointType::IcpGround : LidarPointType::Icp;
+  for (int k = 0; k < 3; ++k) lp.xyz[k] = h.lidar_xyz[k];
+  for (int k = 0; k < 4; ++k) lp.abcd[k] = h.abcd[k];
+  if (lp.type == LidarPointType::IcpGround) lp.color = {255, 255, 0};
+  else if (gate_mode == PCD_GATE_MAPPER_LOCAL) lp.color = {0, 255, 0};
+  else lp.color = {0, 0, 255};
+  lp.dist = h.dist;
+  lp.angle = h.angle;
+  return lp;
+}
+
 inline bool MatchClosestLidarPoints(lidar::PointCloudProcess& pcp, const std::vector<uint64_t>& point3D_ids,
                                     const std::vector<double>& xyz /*3 per point*/,
                                     const std::vector<double>& max_search_range /*1 or n entries*/, int gate_mode,
                                     std::unordered_map<uint64_t, LidarPoint>* lidar_maps) {
   const uint64_t n = point3D_ids.size();
   if (xyz.size() != 3 * n || !pcp.handle()) return false;
-  std::vector<double> lx(3 * n), abcd(4 * n), dist(n), angle(n);
-  std::vector<uint8_t> type(n);
-  pcd_assoc_out out{lx.data(), abcd.data(), type.data(), dist.data(), angle.data(), nullptr, nullptr, nullptr};
-  if (pcd_associate(pcp.handle(), xyz.data(), n, max_search_range.data(), max_search_range.size(), gate_mode, &out) !=
-      PCD_OK)
-    return false;
-  for (uint64_t i = 0; i < n; ++i) {
-    if (type[i] == PCD_LIDAR_NONE) continue;
-    LidarPoint lp;
-    lp.type = type[i] == PCD_LIDAR_ICP_GROUND ? LidarPointType::IcpGround : LidarPointType::Icp;
-    for (int k = 0; k < 3; ++k) lp.xyz[k] = lx[3 * i + k];
-    for (int k = 0; k < 4; ++k) lp.abcd[k] = abcd[4 * i + k];
-    if (lp.type == LidarPointType::IcpGround) lp.color = {255, 255, 0};
-    else if (gate_mode == PCD_GATE_MAPPER_LOCAL) lp.color = {0, 255, 0};
-    else lp.color = {0, 0, 255};
-    lp.dist = dist[i];
-    lp.angle = angle[i];
-    (*lidar_maps)[point3D_ids[i]] = lp;
-  }
+  if (gate_mode != PCD_GATE_CONTROLLER && max_search_range.size() != 1 && max_search_range.size() != n) return false;
+  const bool per_point = max_search_range.size() == n && n > 1;
+  const pcd_assoc_hit* hits = nullptr;
+  uint64_t n_hits = 0;
+  auto fill = [&](uint64_t i, double* q3, double* r) {
+    q3[0] = xyz[3 * i]; q3[1] = xyz[3 * i + 1]; q3[2] = xyz[3 * i + 2];
+    if (!max_search_range.empty()) *r = max_search_range[per_point ? i : 0];
+  };
+  if (!MatchClosestLidarPointsFlat(pcp, n, per_point, gate_mode, fill, &hits, &n_hits)) return false;
+  lidar_maps->reserve(lidar_maps->size() + n_hits);
+  for (uint64_t k = 0; k < n_hits; ++k) (*lidar_maps)[point3D_ids[hits[k].query]] = ToLidarPoint(hits[k], gate_mode);
   return true;
 }
 

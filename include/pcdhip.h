@@ -164,6 +164,27 @@ typedef struct {
 pcd_status pcd_associate(pcd_cloud* c, const double* q_xyz, uint64_t Q, const double* max_range,
                          uint64_t max_range_count, int gate_mode, const pcd_assoc_out* out);
 
+/* Staged host form for the call sites (the drop-in's PCIe path): inputs and results live in PINNED host memory
+ * owned by the cloud handle, and only the associations the reference would have recorded come back, as one
+ * 80-byte record each, in ascending query order:
+ *   pcd_assoc_staging   pinned input buffers for Q queries (valid until the next staging call or destroy); the
+ *                       caller gathers Point3D::XYZ() / the range schedule straight into them
+ *   pcd_associate_staged  H2D (24 B / query) -> search + epilogue -> device-side compaction of type != 0 ->
+ *                       D2H of num_hits records; *hits points into pinned memory valid until the next call
+ * (pcd_associate with caller-owned pageable arrays of 89 B / query stays for convenience: it is PCIe- and
+ * staging-copy-bound, about 10x the device time.) */
+typedef struct {
+  double lidar_xyz[3];   /* LidarPoint::LidarXYZ()                    */
+  double abcd[4];        /* LidarPoint::LidarABCD() after Normalize() */
+  double dist, angle;    /* SetDist / SetAngle                        */
+  uint32_t query;        /* row of q_xyz this association belongs to  */
+  uint8_t type;          /* PCD_LIDAR_ICP | PCD_LIDAR_ICP_GROUND      */
+  uint8_t pad[3];
+} pcd_assoc_hit;
+pcd_status pcd_assoc_staging(pcd_cloud* c, uint64_t Q, double** q_xyz /*[Q][3]*/, double** max_range /*[Q]*/);
+pcd_status pcd_associate_staged(pcd_cloud* c, uint64_t Q, uint64_t max_range_count, int gate_mode,
+                                const pcd_assoc_hit** hits, uint64_t* num_hits);
+
 /* Device form: every pointer in `out` and d_q_xyz / d_max_range are device
  * pointers.  d_keys_in == NULL: run the search; otherwise use these keys
  * (e.g. after a cross-rank MIN) and skip the search.  On a sharded cloud

@@ -138,3 +138,36 @@ def test_associate_device_ignores_foreign_keys(gpu, oracle):
     _compare(merged, out6, ok, exp, 0)
     for s in shards:
         s.close()
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_staged_host_path(gpu, oracle, mode):
+    """pcd_assoc_staging + pcd_associate_staged (pinned staging, device-side compaction): the records are exactly the
+    accepted rows of pcd_associate, in ascending query order; scalar and per-point range; empty batch; re-use."""
+    xyz, nrm = synth.cloud_planes(60000, seed=20240601, patches=20)
+    nrm[::97] = 0.0
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    for Q, seed in ((70000, 1), (5000, 2)):        # large batch (grid path), then a smaller one in the same buffers
+        q = synth.queries(xyz, Q, seed=seed)
+        mr = synth.max_range_schedule(Q, seed=seed)
+        full = c.associate(q, None if mode == 2 else mr, mode)
+        sq, smr = c.staging(Q)
+        sq[:] = q
+        smr[:] = mr
+        hits = c.associate_staged(Q, Q, mode)
+        acc = np.nonzero(full["type"])[0]
+        assert len(hits) == len(acc) and 0 < len(acc) < Q
+        assert np.array_equal(hits["query"], acc) and np.array_equal(hits["type"], full["type"][acc])
+        for k in ("lidar_xyz", "abcd", "dist", "angle"):
+            assert np.array_equal(hits[k], full[k][acc]), k
+        if mode == 0:                                # one range for all
+            smr[0] = 0.4
+            h1 = c.associate_staged(Q, 1, mode)
+            f1 = c.associate(q, 0.4, mode)
+            assert np.array_equal(h1["query"], np.nonzero(f1["type"])[0])
+    assert len(c.associate_staged(0, 1, mode)) == 0
+    far = np.full((10, 3), 1e4)
+    sq, smr = c.staging(10)
+    sq[:] = far; smr[:] = 1.0
+    assert len(c.associate_staged(10, 10, 0)) == 0   # nothing accepted
+    c.close()

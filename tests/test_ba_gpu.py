@@ -184,3 +184,68 @@ def test_camera_blocks(gpu, oracle, model):
     got = ba.evaluate(("H_cam", "g_cam", "E_cam"))
     assert not got["H_cam"].any() and not got["g_cam"].any() and not got["E_cam"].any()
     ba.close()
+
+
+def _pose_tangent_gradient(s, out, res):
+    """g_img re-assembled on the host from the raw blocks: sum over the image's observations of
+    [Jq plus(q) | Jt]^T r (trivial loss, no constant poses in these scenes)"""
+    O = len(s["obs_image"])
+    x = s["poses"][s["obs_image"], :4]
+    plus = np.stack([np.stack([-x[:, 1], -x[:, 2], -x[:, 3]], 1), np.stack([x[:, 0], x[:, 3], -x[:, 2]], 1),
+                     np.stack([-x[:, 3], x[:, 0], x[:, 1]], 1), np.stack([x[:, 2], -x[:, 1], x[:, 0]], 1)], 1)  # [O][4][3]
+    Jp = np.concatenate([np.einsum("ork,okc->orc", out["jac_q"], plus), out["jac_t"]], axis=2)               # [O][2][6]
+    g = np.zeros((s["poses"].shape[0], 6))
+    np.add.at(g, s["obs_image"], np.einsum("orc,or->oc", Jp, res[:2 * O].reshape(-1, 2)))
+    return g
+
+
+@pytest.mark.parametrize("cams,points,shard", [(450, 400_000, None), (5000, 2_000_000, 8)],
+                         ids=["config B: 450 cams / 400k pts / ~2M obs", "config C: one rank's share of 5000 cams / 2M tracks"])
+def test_config_size_properties(gpu, oracle, cams, points, shard):
+    """BASELINE.json's BA sizes -- B (Smith Hall 450: 450 cameras / 400 k points / ~2 M observations / ~350 k LiDAR terms)
+    and one rank's eighth of C (5 000 cameras / 2 M tracks / ~10 M observations, sharded by track as bench.py does) --
+    checked through properties that do not depend on the size: cost = 1/2 |r|^2 of the returned residuals, point and
+    pose gradients = J^T r re-assembled on the host from the returned raw blocks, W = Jp^T JX on a sample, and the
+    oracle's Jet residuals / Jacobians on a track sample."""
+    from pcdhip import dist as pd
+    s = synth.ba_scene(cams, points, seed=41, lidar_frac=0.875, order="image")
+    if shard:
+        s, _ = pd.shard_tracks(s, 3, shard)
+    s["image_const_pose"] = np.zeros(cams, np.uint8)
+    P, O, L = s["points"].shape[0], len(s["obs_image"]), len(s["lidar_point"])
+    assert (P, cams) == ((points // shard if shard else points), s["poses"].shape[0]) and O > 4 * P and L > 0.8 * P
+    ba = gpu.BA(**s)
+    out = ba.evaluate(("cost", "residuals", "jac_q", "jac_t", "jac_X", "jac_lidar", "g_pt", "g_img", "H_pt", "W"))
+    res = out["residuals"]
+    assert np.isfinite(res).all()
+    assert abs(out["cost"][0] - 0.5 * float(res @ res)) <= 1e-10 * out["cost"][0]
+    r2 = res[:2 * O].reshape(-1, 2)
+    g = np.zeros((P, 3))
+    np.add.at(g, s["obs_point"], np.einsum("ork,or->ok", out["jac_X"], r2))
+    np.add.at(g, s["lidar_point"], out["jac_lidar"] * res[2 * O:, None])
+    _close(out["g_pt"], g, 1e-9, "g_pt vs J^T r")
+    _close(out["g_img"], _pose_tangent_gradient(s, out, res), 1e-9, "g_img vs J^T r")
+    H = np.zeros((P, 3, 3))
+    np.add.at(H, s["obs_point"], np.einsum("ora,orb->oab", out["jac_X"], out["jac_X"]))
+    np.add.at(H, s["lidar_point"], np.einsum("la,lb->lab", out["jac_lidar"], out["jac_lidar"]))
+    _close(out["H_pt"], H, 1e-9, "H_pt vs J^T J")
+    # W on a sample of observations
+    sel = np.random.default_rng(5).choice(O, 20000, replace=False)
+    x = s["poses"][s["obs_image"][sel], :4]
+    plus = np.stack([np.stack([-x[:, 1], -x[:, 2], -x[:, 3]], 1), np.stack([x[:, 0], x[:, 3], -x[:, 2]], 1),
+                     np.stack([-x[:, 3], x[:, 0], x[:, 1]], 1), np.stack([x[:, 2], -x[:, 1], x[:, 0]], 1)], 1)
+    Jp = np.concatenate([np.einsum("ork,okc->orc", out["jac_q"][sel], plus), out["jac_t"][sel]], axis=2)
+    _close(out["W"][sel], np.einsum("ora,orb->oab", Jp, out["jac_X"][sel]), 1e-9, "W vs Jp^T JX")
+    # oracle (Jets) on the tracks of the first 4000 points
+    keep = s["obs_point"] < 4000
+    lk = s["lidar_point"] < 4000
+    sub = dict(s)
+    sub["points"] = s["points"][:4000]
+    sub["obs_image"], sub["obs_point"], sub["obs_xy"] = s["obs_image"][keep], s["obs_point"][keep], s["obs_xy"][keep]
+    sub["lidar_point"], sub["lidar_abcd"], sub["lidar_weight"] = s["lidar_point"][lk], s["lidar_abcd"][lk], s["lidar_weight"][lk]
+    ores, oJq, oJt, oJX, _, oJL = oracle.BA(**sub).evaluate_raw()
+    _close(res[:2 * O].reshape(-1, 2)[keep].ravel(), ores[:2 * int(keep.sum())], 1e-9, "residuals vs oracle")
+    _close(out["jac_q"][keep], oJq, 1e-9, "Jq vs oracle")
+    _close(out["jac_X"][keep], oJX, 1e-9, "JX vs oracle")
+    _close(res[2 * O:][lk], ores[2 * int(keep.sum()):], 1e-9, "lidar residuals vs oracle")
+    ba.close()

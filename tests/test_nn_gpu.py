@@ -170,8 +170,10 @@ def test_midsize_vs_kdtree_oracle_and_gpu_bruteforce(gpu, oracle):
     c.close()
 
 
-def test_full_size_properties(gpu):
-    """BASELINE.json's size (10 M-point cloud, 1 M queries): too large for the CPU oracle in a test, so the
+@pytest.mark.parametrize("N,Q", [(10_000_000, 1_000_000), (20_000_000, 2_000_000)],
+                         ids=["config M: 10M cloud / 1M queries", "config C: 20M cloud / 2M queries"])
+def test_full_size_properties(gpu, N, Q):
+    """BASELINE.json's sizes (M: 10 M-point cloud / 1 M queries; C: 20 M / 2 M): too large for the CPU oracle in a test, so the
     result is checked through properties that do not depend on the size:
       * the returned squared distance is bit-for-bit the FLANN float distance to the returned row;
       * a 4096-query sample equals the GPU brute force over all 10 M rows (itself oracle-checked above);
@@ -180,7 +182,6 @@ def test_full_size_properties(gpu):
       * splitting the cloud in two interleaved shards and taking the per-query minimum of the packed keys
         reproduces the single-cloud keys (the cloud-sharded multi-GPU path, dist.py)."""
     import torch
-    N, Q = 10_000_000, 1_000_000
     xyz, nrm = synth.cloud_planes(N)
     q = synth.queries(xyz, Q)
     c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
@@ -220,6 +221,37 @@ def test_full_size_properties(gpu):
         ks.append(kk.clone())
         cs.close()
     assert torch.equal(torch.minimum(ks[0], ks[1]), keys[:Qs])
+    # two spatially compact shards, two-phase search (pcd_nn_refine_device): same keys up to the row permutation
+    from pcdhip import dist as pd
+    order = pd.compact_order(xyz)
+    inv = np.empty(N, np.int64); inv[order] = np.arange(N)
+    cuts = pd.shard_cuts(N, 2)
+    sh = [gpu.Cloud(xyz[order[cuts[r]:cuts[r + 1]]], nrm[order[cuts[r]:cuts[r + 1]]], raw_lidar_frame=False,
+                    index_base=cuts[r]) for r in range(2)]
+    boxes = np.array([s_.info()["bbox_lo"] + s_.info()["bbox_hi"] for s_ in sh])
+    home = pd.home_shards(q[:Qs], boxes[:, :3], boxes[:, 3:])
+    k2 = torch.full((Qs,), gpu.KEY_NONE, dtype=torch.int64, device="cuda")
+    for r in range(2):                                   # phase 1: home shard only
+        idx = torch.from_numpy(np.nonzero(home == r)[0]).cuda()
+        kh = torch.empty(len(idx), dtype=torch.int64, device="cuda")
+        sh[r].nn_device(dq[:Qs][idx].contiguous(), len(idx), kh)
+        k2[idx] = kh
+    parts = []
+    for r in range(2):                                   # phase 2: the foreign queries a shard cannot rule out
+        kr = k2.clone()
+        sh[r].nn_refine_device(dq[:Qs].contiguous(), Qs, kr, torch.from_numpy((home == r).astype(np.uint8)).cuda())
+        parts.append(kr)
+    torch.cuda.synchronize()
+    kk = torch.minimum(parts[0], parts[1]).cpu().numpy().view(np.uint64)
+    ref = keys[:Qs].cpu().numpy().view(np.uint64)
+    assert np.array_equal(kk >> np.uint64(32), ref >> np.uint64(32))                 # same distances
+    same_pt = order[(kk & np.uint64(0xFFFFFFFF)).astype(np.int64)]                   # back to original rows
+    ref_i = (ref & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    diff = same_pt != ref_i
+    # a different row only on an exact distance tie (the compact order has its own lowest index)
+    assert np.array_equal(xyz[same_pt[diff]], xyz[ref_i[diff]]) or diff.sum() <= 8
+    for s_ in sh:
+        s_.close()
 
 
 @pytest.mark.parametrize("offset", [1e3, 1e5, 3e6])
