@@ -82,6 +82,15 @@ def cpu_baseline(xyz, nrm, q, mr, scene, nq, npts):
     timed, for NN and for the Jet evaluation; `value` is the all-cores figure, the others are listed beside it."""
     from oracle import pyoracle as po
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:                                       # cgroup v2 CPU quota of the box ("max" = none)
+        qv, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if qv != "max":
+            quota = float(qv) / float(per)
+            cores = max(1, min(cores, int(round(quota))))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, 64)                     # threads actually used
     t0 = time.time()
     kd = po.KDTree(xyz)                      # FLANN-style single tree, leaf 15
     t_build = time.time() - t0
@@ -114,6 +123,8 @@ def cpu_baseline(xyz, nrm, q, mr, scene, nq, npts):
     per_point = lambda tnn, tba, n: tnn / nq + tba / n
     v_all = 1.0 / per_point(t_nnc, t_bac, nptc)
     return dict(value=v_all, unit="queries/s", cores=cores, kind="port",
+                host=f"{len(os.sched_getaffinity(0))} logical CPUs visible, cgroup quota {quota if quota else 'none'}, "
+                     f"{cores} threads used",
                 sample=f"kd-tree over the full {xyz.shape[0]}-pt cloud (build {t_build:.1f}s, not counted); {nq} queries "
                        f"NN+association: {t_nn1:.2f}s on 1 thread, {t_nnc:.2f}s on {cores}; BA Jet evaluation + "
                        f"residual-only pass: {npts} tracks / {nobs1} obs {t_ba1:.2f}s on 1 thread, "
