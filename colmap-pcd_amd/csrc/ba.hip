@@ -47,6 +47,9 @@ struct BaDev {
   const uint32_t* img_obs_start;  // [I+1]
   const int* img_pt;              // [O] point of the e-th observation of the image-major order
   const uint32_t* img_obs;        // [O] its index in the caller's observation order (W is written there)
+  const uint32_t* seg_img;        // [nseg] image of each segment of <= kImgSeg observations (image-major order)
+  const uint32_t* seg_begin;      // [nseg+1] first observation (image-major position) of each segment
+  const uint32_t* img_seg_start;  // [I+1] segments of each image
   const uint8_t* cam_refine;      // [cam_params_len] 1 = parameter optimised (nullptr: all constant)
   const uint32_t* cam_img_start;  // [C+1] images of each camera (CSR, ascending image index)
   const uint32_t* cam_img_list;
@@ -234,18 +237,23 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
 // in registers anyway (no second sweep).  When the caller's observations are image-major (the order
 // AddImageToProblem creates them in, optim/bundle_adjustment.cc:814-919) the 144-B blocks of consecutive
 // lanes are adjacent in memory.
+// Work item = one SEGMENT of <= kImgSeg observations of an image (an image per workgroup left a quarter of the chip
+// idle on a 1000-image scene and nearly all of it on a 25-image one); the 27 partial sums of a segment go to
+// `partial` and k_ba_images_reduce adds the segments of an image in ascending order: still no atomics, still
+// bitwise reproducible.
+constexpr uint32_t kImgSeg = 1024;
 template <int MODEL, bool WANT_W>
-__global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__ Himg, double* __restrict__ gimg,
-                                                   double* __restrict__ W_o) {
+__global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__ partial, double* __restrict__ W_o) {
   __shared__ __attribute__((aligned(16))) double s_w[WANT_W ? 4 : 1][WANT_W ? 64 * 18 : 2];
-  const int im = blockIdx.x;
+  const int im = (int)d.seg_img[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool cpose = d.image_const_pose && d.image_const_pose[im];
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
   const unsigned tmask = d.image_const_tvec ? d.image_const_tvec[im] : 0u;
-  const uint32_t e_beg = d.img_obs_start[im], e_end = d.img_obs_start[im + 1];
+  const uint32_t e_beg = d.seg_begin[blockIdx.x];
+  const uint32_t e_end = min(d.seg_begin[blockIdx.x + 1], d.img_obs_start[im + 1]);   // segments never span images
   if (!cpose || WANT_W) {
     // every lane runs every iteration (the W store below is a whole-wavefront operation)
     for (uint32_t e0 = e_beg; e0 < e_end; e0 += 256) {
@@ -315,17 +323,26 @@ __global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__
     if (lane == 0) s_a[wave][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 27) {
-    const double v = (s_a[0][threadIdx.x] + s_a[1][threadIdx.x]) + (s_a[2][threadIdx.x] + s_a[3][threadIdx.x]);
-    if (threadIdx.x >= 21) {
-      if (gimg) gimg[6 * (size_t)im + (threadIdx.x - 21)] = v;
-    } else if (Himg) {
-      int a = 0, k = threadIdx.x;  // unpack the upper-triangle index
-      while (k >= 6 - a) { k -= 6 - a; ++a; }
-      const int c = a + k;
-      Himg[36 * (size_t)im + 6 * a + c] = v;
-      Himg[36 * (size_t)im + 6 * c + a] = v;
-    }
+  if (threadIdx.x < 27)
+    partial[27 * (size_t)blockIdx.x + threadIdx.x] =
+        (s_a[0][threadIdx.x] + s_a[1][threadIdx.x]) + (s_a[2][threadIdx.x] + s_a[3][threadIdx.x]);
+}
+
+// segments of an image added in ascending order -> 6x6 block (symmetric) + gradient
+__global__ __launch_bounds__(64) void k_ba_images_reduce(BaDev d, const double* __restrict__ partial,
+                                                         double* __restrict__ Himg, double* __restrict__ gimg) {
+  const int im = blockIdx.x * 2 + (threadIdx.x >> 5), k = threadIdx.x & 31;
+  if (im >= d.I || k >= 27) return;
+  double v = 0.0;
+  for (uint32_t sgm = d.img_seg_start[im]; sgm < d.img_seg_start[im + 1]; ++sgm) v += partial[27 * (size_t)sgm + k];
+  if (k >= 21) {
+    if (gimg) gimg[6 * (size_t)im + (k - 21)] = v;
+  } else if (Himg) {
+    int a = 0, kk = k;  // unpack the upper-triangle index
+    while (kk >= 6 - a) { kk -= 6 - a; ++a; }
+    const int c = a + kk;
+    Himg[36 * (size_t)im + 6 * a + c] = v;
+    Himg[36 * (size_t)im + 6 * c + a] = v;
   }
 }
 
@@ -690,6 +707,9 @@ struct pcd_ba {
   DevBuf<uint8_t> image_const_pose, image_const_tvec, point_const;
   bool has_cpose = false, has_ctvec = false, has_cpt = false;
   DevBuf<uint32_t> slice_start, pt_lidar_start, pt_lidar_list, img_obs_start, img_obs, cam_img_start, cam_img_list;
+  DevBuf<uint32_t> seg_img, seg_begin, img_seg_start;
+  uint32_t nseg = 0;
+  DevBuf<double> img_partial;
   DevBuf<uint8_t> cam_refine;
   bool has_refine = false;
   DevBuf<double> cam_partial;
@@ -708,6 +728,7 @@ struct pcd_ba {
     d.pt_order = pt_order.p; d.slice_start = slice_start.p; d.sell_img = sell_img.p; d.sell_xy = sell_xy.p;
     d.pt_lidar_start = pt_lidar_start.p; d.pt_lidar_list = pt_lidar_list.p;
     d.img_obs_start = img_obs_start.p; d.img_pt = img_pt.p; d.img_xy = img_xy.p; d.img_obs = img_obs.p;
+    d.seg_img = seg_img.p; d.seg_begin = seg_begin.p; d.img_seg_start = img_seg_start.p;
     d.cam_refine = has_refine ? cam_refine.p : nullptr; d.cam_img_start = cam_img_start.p; d.cam_img_list = cam_img_list.p;
     d.C = C; d.cam_k = (uniform_model >= 0 && uniform_model <= 4) ? cam_num_params(uniform_model) : PCD_CAM_JAC_STRIDE;
     d.I = I; d.P = P; d.nslices = nslices; d.O = O; d.L = L; d.loss_type = loss_type; d.loss_scale = loss_scale;
@@ -846,6 +867,19 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
       img_xy[2 * e + 1] = d->obs_xy[2 * (size_t)o + 1];
     }
     UP(img_obs_start, st.data(), st.size());
+    {  // segments of <= kImgSeg observations, never spanning two images (an image without observations has none)
+      std::vector<uint32_t> seg_img, seg_begin, img_seg_start(b->I + 1, 0);
+      for (int i = 0; i < b->I; ++i) {
+        img_seg_start[i] = (uint32_t)seg_img.size();
+        for (uint32_t e = st[i]; e < st[i + 1]; e += kImgSeg) { seg_img.push_back((uint32_t)i); seg_begin.push_back(e); }
+      }
+      img_seg_start[b->I] = (uint32_t)seg_img.size();
+      b->nseg = (uint32_t)seg_img.size();
+      seg_begin.push_back((uint32_t)b->O);
+      UP(seg_img, seg_img.data(), seg_img.size());
+      UP(seg_begin, seg_begin.data(), seg_begin.size());
+      UP(img_seg_start, img_seg_start.data(), img_seg_start.size());
+    }
     {  // images of each camera, ascending
       std::vector<uint32_t> cst, cli;
       build_csr(d->image_camera, (uint64_t)b->I, b->C, cst, cli);
@@ -915,14 +949,18 @@ pcd_status pcd_ba_evaluate_device(pcd_ba* b, const pcd_ba_out* o, void* stream) 
   // W rides on the image pass when that runs anyway (normal-equation mode); otherwise the raw kernel fills it
   const bool w_fused = o->W && (o->H_img || o->g_img) && b->O;
   if (o->H_img || o->g_img) {
+    PCD_TRY(b->img_partial.reserve(27 * (size_t)std::max(b->nseg, 1u)));
     ScopedKernelTimer t(w_fused ? "ba_images_w" : "ba_images", s);
-    if (w_fused) {
-      PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_images<M, true>), dim3(b->I), dim3(256), 0, s, d, o->H_img,
-                                                 o->g_img, o->W));
-    } else {
-      PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_images<M, false>), dim3(b->I), dim3(256), 0, s, d, o->H_img,
-                                                 o->g_img, (double*)nullptr));
+    if (b->nseg) {
+      if (w_fused) {
+        PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_images<M, true>), dim3(b->nseg), dim3(256), 0, s, d,
+                                                   b->img_partial.p, o->W));
+      } else {
+        PCD_BA_DISPATCH(model, hipLaunchKernelGGL((k_ba_images<M, false>), dim3(b->nseg), dim3(256), 0, s, d,
+                                                   b->img_partial.p, (double*)nullptr));
+      }
     }
+    hipLaunchKernelGGL(k_ba_images_reduce, dim3(div_up(b->I, 2)), dim3(64), 0, s, d, b->img_partial.p, o->H_img, o->g_img);
   }
   double* const W_raw = w_fused ? nullptr : o->W;
   if ((o->residuals || o->jac_q || o->jac_t || o->jac_X || W_raw) && b->O) {

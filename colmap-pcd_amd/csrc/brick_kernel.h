@@ -32,6 +32,7 @@ namespace pcd {
 #define PCD_BRICK_MINWAVES 4
 #endif
 constexpr int kTile = PCD_KTILE;
+constexpr int kFbChunk = 64;   // fallback-list slots a wavefront reserves per atomic (>= queries per item)
 static_assert(kTile == 256, "a tile is 4 DMA instructions (128/192-point tiles were measured slower and removed)");
 // timing-only ablations (results are then wrong): compiled in only with -DPCD_ABLATE (tools/nn_ablate.py builds
 // such a variant); in the shipped library the masks are 0 and every `flags & kAblate*` folds away.
@@ -154,6 +155,7 @@ __device__ __forceinline__ void compare_point(const f32x4 p, const float (&qx)[8
 
 struct BrickMeta {   // per-group loads issued one group ahead
   float4 q;          // lane < cnt: query (x,y,z, bits(query id))
+  uint64_t prior;    // lane < cnt: the key the query came with (kKeyInit, or another shard's result when refining)
   uint32_t s, e;     // lane < nrows: point range of the lane's cell row
 };
 
@@ -172,6 +174,7 @@ __device__ __forceinline__ void brick_region(const GridParams& g, const BrickPar
 // y and z to whole quads (a superset; proven_bound keeps using the un-grown box, which is conservative).
 __device__ __forceinline__ BrickMeta brick_load_meta(const GridParams& g, const BrickParams& b, const uint4 it,
                                                      const float4* __restrict__ qsorted,
+                                                     const uint64_t* __restrict__ ksorted,
                                                      const uint32_t* __restrict__ cell_start) {
   const int lane = threadIdx.x & 63;
   BrickMeta m;
@@ -180,6 +183,7 @@ __device__ __forceinline__ BrickMeta brick_load_meta(const GridParams& g, const 
   // falls back to s_waitcnt vmcnt(0) at the first use -- which would serialise the prefetch.
   const int cnt = item_count(it);  // >= 1
   m.q = qsorted[it.x + (lane < cnt ? lane : cnt - 1)];
+  m.prior = ksorted[it.x + (lane < cnt ? lane : cnt - 1)];   // brick-sorted copy: no dependent gather at the item's end
   int c0[3], c1[3];
   brick_region(g, b, it, c0, c1);
   const int yq0 = c0[1] >> 1, zq0 = c0[2] >> 1;
@@ -200,6 +204,7 @@ template <int G>
 __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams g, BrickParams b, const float4* __restrict__ sorted,
                                                   const uint32_t* __restrict__ cell_start,
                                                   const float4* __restrict__ qsorted,
+                                                  const uint64_t* __restrict__ ksorted,
                                                   const uint4* __restrict__ items, NnCounters* __restrict__ ctr,
                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ fb_list,
                                                   int flags) {
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
   const uint32_t nitems = ctr->nitems;
   const uint32_t nwaves = gridDim.x * 4;
   unsigned long long st_staged = 0, st_pairs = 0, st_groups = 0;
+  uint32_t fb_base = 0, fb_left = 0;   // this wavefront's current chunk of the fallback list
 
   // XCD-aware work split: blocks b, b+8, b+16, ... share an XCD (and its 4 MiB L2), so each of the 8
   // block classes walks its own contiguous eighth of the item list (items are in brick order, x fastest):
@@ -229,13 +235,13 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
   }
   if (item >= item_end) return;
   uint4 it0 = items[item];
-  BrickMeta m0 = brick_load_meta(g, b, it0, qsorted, cell_start);
+  BrickMeta m0 = brick_load_meta(g, b, it0, qsorted, ksorted, cell_start);
   uint4 it1 = items[min(item + stride, item_end - 1)];
 
   for (; item < item_end; item += stride) {
     // ---- prefetch: metadata of the next group, item record of the one after ----
     // (unconditional, clamped to the last item: see brick_load_meta)
-    const BrickMeta m1 = brick_load_meta(g, b, it1, qsorted, cell_start);
+    const BrickMeta m1 = brick_load_meta(g, b, it1, qsorted, ksorted, cell_start);
     const uint4 it2 = items[min(item + 2 * stride, item_end - 1)];
 
     // ---- current group ----
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
     if (lane < (int)cnt) {
       const uint32_t my_qi = __float_as_uint(m0.q.w);
       // the key the query came with: kKeyInit for a plain query, another shard's result for pcd_nn_refine_device
-      mine = min_u64(mine, keys[my_qi]);
+      mine = min_u64(mine, m0.prior);
       const double bound = proven_bound(g, m0.q.x, m0.q.y, m0.q.z, c0, c1);
       const double bd = (double)__uint_as_float((uint32_t)(mine >> 32));
       unproven = !(bd < bound) && !(flags & kAblateFallback);
@@ -392,10 +398,19 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
     }
     const unsigned long long um = __ballot(unproven);
     if (um) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&ctr->fb_count, (uint32_t)__popcll(um));
-      base = __shfl(base, 0);
-      if (unproven) fb_list[base + __popcll(um & ((1ull << lane) - 1))] = __float_as_uint(m0.q.w);
+      // the wavefront appends to the fallback list inside chunks of kFbChunk slots it reserves with ONE returning
+      // atomic each (an atomic per item exposed its latency on every fourth item); unused slots of a chunk keep
+      // the 0xFFFFFFFF the list was filled with and are skipped by k_nn_fallback
+      const uint32_t k = (uint32_t)__popcll(um);
+      if (k > fb_left) {   // wave-uniform
+        uint32_t nb = 0;
+        if (lane == 0) nb = atomicAdd(&ctr->fb_count, (uint32_t)kFbChunk);
+        fb_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+        fb_left = kFbChunk;
+      }
+      if (unproven) fb_list[fb_base + __popcll(um & ((1ull << lane) - 1))] = __float_as_uint(m0.q.w);
+      fb_base += k;
+      fb_left -= k;
     }
     if (collect_stats) { st_staged += T; st_pairs += (unsigned long long)T * cnt; st_groups += 1; }
     it0 = it1; it1 = it2; m0 = m1;

@@ -198,9 +198,10 @@ struct ItemFlag {     // j -> 1 if a work item starts at j
 template <int G>
 __global__ void k_brick_emit(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                              const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ item_idx,
-                             const float4* __restrict__ qf4, uint32_t Q, uint32_t nbricks, uint32_t nb0, uint32_t nb1,
-                             uint4* __restrict__ items, float4* __restrict__ qsorted, uint32_t* __restrict__ fb_list,
-                             NnCounters* __restrict__ ctr) {
+                             const float4* __restrict__ qf4, const uint64_t* __restrict__ keys_in, uint32_t Q,
+                             uint32_t nbricks, uint32_t nb0, uint32_t nb1, uint4* __restrict__ items,
+                             float4* __restrict__ qsorted, uint64_t* __restrict__ ksorted,
+                             uint32_t* __restrict__ fb_list, NnCounters* __restrict__ ctr) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= Q) return;
   const uint32_t key = keys[j], v = vals[j];
@@ -209,6 +210,7 @@ __global__ void k_brick_emit(const uint32_t* __restrict__ keys, const uint32_t* 
     float4 q = qf4[v];
     q.w = __uint_as_float(v);          // brick-sorted query record {x, y, z, bits(query id)}
     qsorted[j] = q;
+    ksorted[j] = keys_in[v];           // the key the query came with, in the same order
     if (is_item) {
       uint32_t cnt = 1;
       while (cnt < (uint32_t)G && j + cnt < Q && keys[j + cnt] == key) ++cnt;
@@ -290,8 +292,16 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
   const int top = py.nlev - 1;  // >= 1
   const int ci = lane & 3, cj = (lane >> 2) & 3, ck = lane >> 4;
   unsigned long long st_pts = 0, st_q = 0;
-  for (uint32_t e = blockIdx.x * 4 + wave; e < count; e += nwaves) {
+  // The list is filled in chunks of 64 slots (brick_kernel.h kFbChunk), each used from its first slot on, the rest
+  // left at 0xFFFFFFFF.  Wavefront w takes every nwaves-th entry of the TRANSPOSED order (slot-in-chunk major):
+  // taking every nwaves-th entry of the list itself would give a wavefront the same slot of every chunk, and the
+  // low slots -- always used -- 2-3x the work of the high ones.
+  const uint32_t nch = (count + 63u) / 64u;
+  for (uint32_t t = blockIdx.x * 4 + wave; t < (list ? nch * 64u : count); t += nwaves) {
+    const uint32_t e = list ? (t % nch) * 64u + t / nch : t;
+    if (e >= count) continue;
     const uint32_t qi = list ? list[e] : e;
+    if (qi == 0xFFFFFFFFu) continue;   // unused slot of a wavefront's chunk
     const float4 q = qf4[qi];
     if (q.w == 0.f) continue;  // not finite: stays "not found"
     const float qx = q.x, qy = q.y, qz = q.z;
@@ -406,7 +416,11 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   if ((B + 2 * R) * (B + 2 * R) > kMaxRows) { B = 2; R = 2; }
   const BrickParams b = make_bricks(g, B, R);
   PCD_TRY(sc->qsorted.reserve(Q));
-  PCD_TRY(sc->fb_list.reserve(Q));
+  PCD_TRY(sc->ksorted.reserve(Q));
+  // fallback list: one slot per query + the chunk slack of every wavefront of the brick kernel (brick_kernel.h)
+  const size_t fb_cap = Q + (size_t)256 * g_brick_blocks_per_cu * 4 * kFbChunk;
+  PCD_TRY(sc->fb_list.reserve(fb_cap));
+  PCD_HIP_TRY(hipMemsetAsync(sc->fb_list.p, 0xFF, fb_cap * sizeof(uint32_t), s));
   PCD_TRY(sc->bk_keys.reserve(2 * Q));
   PCD_TRY(sc->bk_vals.reserve(2 * Q));
   PCD_TRY(sc->bk_run.reserve(Q));
@@ -422,6 +436,8 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     while (end_bit < 32 && ((uint64_t)1 << end_bit) <= (uint64_t)b.nbricks + 1) ++end_bit;
     size_t tb = 0;
     // rocPRIM's default takes its merge sort (log2(Q / block) launches) up to 2^20 items: Onesweep above 32 k
+// (Onesweep with 10-12-bit digits -- two passes over the 23-bit brick ids instead of three -- does not fit:
+    //  rocPRIM's block ranking then needs 192 KiB - 2 MiB of LDS)
     using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                                rocprim::default_config, 32768>;
     PCD_HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tb, k0, k1, v0, v1, (unsigned)Q, 0u, end_bit, s));
@@ -437,14 +453,14 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     PCD_TRY(sc->tmp.reserve(tb));
     PCD_HIP_TRY(rocprim::exclusive_scan(sc->tmp.p, tb, flags, sc->bk_item.p, 0u, (size_t)Q, rocprim::plus<uint32_t>(), s));
     hipLaunchKernelGGL(k_brick_emit<G>, dim3(div_up(Q, 256)), dim3(256), 0, s, k1, v1, sc->bk_run.p, sc->bk_item.p,
-                       sc->qf4.p, (uint32_t)Q, b.nbricks, (uint32_t)b.nb[0], (uint32_t)b.nb[1], sc->items.p,
-                       sc->qsorted.p, sc->fb_list.p, sc->counters.p);
+                       sc->qf4.p, d_keys, (uint32_t)Q, b.nbricks, (uint32_t)b.nb[0], (uint32_t)b.nb[1], sc->items.p,
+                       sc->qsorted.p, sc->ksorted.p, sc->fb_list.p, sc->counters.p);
   }
   {
     ScopedKernelTimer t("nn_brick", s);
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(div_up(Q, G), 4) + 1, 256 * (uint64_t)g_brick_blocks_per_cu);
     hipLaunchKernelGGL(k_nn_brick<G>, dim3(blocks), dim3(256), 0, s, g, b, c->sorted.p, c->cell_start.p,
-                       sc->qsorted.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p, g_collect_stats);
+                       sc->qsorted.p, sc->ksorted.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p, g_collect_stats);
   }
   {
     ScopedKernelTimer t("nn_fallback", s);

@@ -16,6 +16,7 @@ struct QueryScratch {
   DevBuf<uint32_t> bk_keys, bk_vals;   // (brick id, query id) pairs, unsorted | sorted halves
   DevBuf<uint32_t> bk_run, bk_item;    // per sorted position: start of its run, index of the item starting there
   DevBuf<float4> qsorted;      // brick-sorted query records {x,y,z,bits(query id)}
+  DevBuf<uint64_t> ksorted;    // their incoming keys, same order
   DevBuf<uint4> items;         // {first query, brick x, brick y, brick z | count << 28}
   DevBuf<uint32_t> fb_list;
   DevBuf<NnCounters> counters;
