@@ -186,27 +186,30 @@ __global__ __launch_bounds__(256) void k_ba_points(BaDev d, double* __restrict__
 // summation order, hence the last bits, differ from the cost the Jacobian pass reports).
 template <int MODEL>
 __global__ __launch_bounds__(256) void k_ba_cost(BaDev d, double* __restrict__ cost_partial) {
-  const uint64_t i = blockIdx.x * (uint64_t)256 + threadIdx.x;
+  // grid-stride over the residual blocks with a FIXED grid (kCostBlocks): the assignment of blocks to threads and
+  // the order of the per-thread and per-workgroup sums do not depend on anything but the problem size
   double cost = 0.0;
-  if (i < d.O) {
-    const int im = d.obs_image[i], pt = d.obs_point[i];
-    const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
-    ReprojBlock b;
-    double q[4];
-    eval_block<MODEL>(d, im, X, d.obs_xy[2 * i], d.obs_xy[2 * i + 1], b, q);
-    double rho0, rho1;
-    loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
-    cost = 0.5 * rho0;
-  } else if (i < d.O + d.L) {
-    const uint64_t l = i - d.O;
-    const int pt = d.lidar_point[l];
-    const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
-    const double abcd[4] = {d.lidar_abcd[4 * l], d.lidar_abcd[4 * l + 1], d.lidar_abcd[4 * l + 2], d.lidar_abcd[4 * l + 3]};
-    double r, J[3];
-    lidar_eval(X, abcd, d.lidar_w[l], 0, r, J);
-    double rho0, rho1;
-    loss_eval(d.loss_type, d.loss_scale, r * r, rho0, rho1);
-    cost = 0.5 * rho0;
+  for (uint64_t i = blockIdx.x * (uint64_t)256 + threadIdx.x; i < d.O + d.L; i += (uint64_t)gridDim.x * 256) {
+    if (i < d.O) {
+      const int im = d.obs_image[i], pt = d.obs_point[i];
+      const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
+      ReprojBlock b;
+      double q[4];
+      eval_block<MODEL>(d, im, X, d.obs_xy[2 * i], d.obs_xy[2 * i + 1], b, q);
+      double rho0, rho1;
+      loss_eval(d.loss_type, d.loss_scale, b.r[0] * b.r[0] + b.r[1] * b.r[1], rho0, rho1);
+      cost += 0.5 * rho0;
+    } else {
+      const uint64_t l = i - d.O;
+      const int pt = d.lidar_point[l];
+      const double X[3] = {d.points[3 * (size_t)pt], d.points[3 * (size_t)pt + 1], d.points[3 * (size_t)pt + 2]};
+      const double abcd[4] = {d.lidar_abcd[4 * l], d.lidar_abcd[4 * l + 1], d.lidar_abcd[4 * l + 2], d.lidar_abcd[4 * l + 3]};
+      double r, J[3];
+      lidar_eval(X, abcd, d.lidar_w[l], 0, r, J);
+      double rho0, rho1;
+      loss_eval(d.loss_type, d.loss_scale, r * r, rho0, rho1);
+      cost += 0.5 * rho0;
+    }
   }
   __shared__ double s_c[256];
   s_c[threadIdx.x] = cost;
@@ -217,12 +220,15 @@ __global__ __launch_bounds__(256) void k_ba_cost(BaDev d, double* __restrict__ c
   }
   if (threadIdx.x == 0) cost_partial[blockIdx.x] = s_c[0];
 }
+constexpr unsigned kCostBlocks = 2048;   // 8 workgroups per CU; 2048 partial sums for k_sum_partials
 
 __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int n, double* __restrict__ out) {
   __shared__ double s_c[256];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
-  s_c[threadIdx.x] = acc;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four loads in flight per thread; the order is fixed
+  int i = threadIdx.x;
+  for (; i + 768 < n; i += 1024) { a0 += partial[i]; a1 += partial[i + 256]; a2 += partial[i + 512]; a3 += partial[i + 768]; }
+  for (; i < n; i += 256) a0 += partial[i];
+  s_c[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) s_c[threadIdx.x] += s_c[threadIdx.x + off];
@@ -934,7 +940,8 @@ pcd_status pcd_ba_evaluate_device(pcd_ba* b, const pcd_ba_out* o, void* stream) 
   const int model = b->uniform_model;
   if (o->cost || o->H_pt || o->g_pt) {
     const bool want_blocks = o->H_pt || o->g_pt;
-    const unsigned blocks = want_blocks ? div_up((size_t)b->nslices * 64, 256) : std::max(1u, div_up(b->O + b->L, 256));
+    const unsigned blocks = want_blocks ? div_up((size_t)b->nslices * 64, 256)
+                                        : std::max(1u, std::min(kCostBlocks, div_up(b->O + b->L, 256)));
     {
       ScopedKernelTimer t(want_blocks ? "ba_points" : "ba_points_cost", s);
       if (want_blocks) {

@@ -210,7 +210,8 @@ __global__ void k_brick_emit(const uint32_t* __restrict__ keys, const uint32_t* 
     float4 q = qf4[v];
     q.w = __uint_as_float(v);          // brick-sorted query record {x, y, z, bits(query id)}
     qsorted[j] = q;
-    ksorted[j] = keys_in[v];           // the key the query came with, in the same order
+    // the key the query came with, in the same order (a plain query comes with kKeyInit: no gather)
+    ksorted[j] = keys_in ? keys_in[v] : kKeyInit;
     if (is_item) {
       uint32_t cnt = 1;
       while (cnt < (uint32_t)G && j + cnt < Q && keys[j + cnt] == key) ++cnt;
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
 static int g_brick_B = 2, g_brick_R = 2, g_collect_stats = 0, g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
 
 template <int G>
-static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t* d_keys, hipStream_t s) {
+static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t* d_keys, hipStream_t s, bool refine) {
   const GridParams& g = c->grid;
   int B = g_brick_B, R = g_brick_R;
   if ((B + 2 * R) * (B + 2 * R) > kMaxRows) { B = 2; R = 2; }
@@ -453,7 +454,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     PCD_TRY(sc->tmp.reserve(tb));
     PCD_HIP_TRY(rocprim::exclusive_scan(sc->tmp.p, tb, flags, sc->bk_item.p, 0u, (size_t)Q, rocprim::plus<uint32_t>(), s));
     hipLaunchKernelGGL(k_brick_emit<G>, dim3(div_up(Q, 256)), dim3(256), 0, s, k1, v1, sc->bk_run.p, sc->bk_item.p,
-                       sc->qf4.p, d_keys, (uint32_t)Q, b.nbricks, (uint32_t)b.nb[0], (uint32_t)b.nb[1], sc->items.p,
+                       sc->qf4.p, refine ? d_keys : (const uint64_t*)nullptr, (uint32_t)Q, b.nbricks, (uint32_t)b.nb[0], (uint32_t)b.nb[1], sc->items.p,
                        sc->qsorted.p, sc->ksorted.p, sc->fb_list.p, sc->counters.p);
   }
   {
@@ -506,7 +507,7 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
                          c->blk_aabb.p, sc->qf4.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)Q,
                          d_keys, sc->counters.p, g_collect_stats);
     } else if (algo == PCD_NN_AUTO || algo == PCD_NN_GRID) {
-      PCD_TRY(run_grid<8>(c, sc, Q, d_keys, s));
+      PCD_TRY(run_grid<8>(c, sc, Q, d_keys, s, refine));
     } else {
       set_error("unknown nn algo %d", algo);
       return PCD_ERR_INVALID;
