@@ -17,7 +17,7 @@ residuals + ambient Jacobian blocks of every residual block, then a residual-onl
 region and reported as ba_raw_iter_ms.
 
 N > 1 (one process per GPU, torch.distributed / RCCL): STRONG scaling of the same workload -- the cloud is
-replicated (160 MB of 288 GB), the 1 M queries are split into N contiguous ranges and the BA scene into N track
+replicated (160 MB of 288 GB), the 1 M queries are split into N spatial slabs and the BA scene into N track
 shards (a rank owns points p = rank mod N with all their observations and LiDAR terms, so point blocks and W are
 complete locally); the per-image blocks are partial sums: one RCCL all-reduce (sum, f64) of I*42 doubles per
 Jacobian pass and one of the cost per pass.  No collective on the NN path.  The cloud-sharded NN variant of
@@ -170,6 +170,12 @@ def main():
     mr_all = synth.max_range_schedule(a.queries, seed=5)
     scene = synth.ba_scene(a.cams, a.points, seed=11, order="image")   # observations in AddImageToProblem order
     Qtot = a.queries
+    if world > 1:
+        # the split is SPATIAL: a rank gets a slab of the queries (contiguous range of a coarse-cell order), so the
+        # bricks it works on are as densely populated as on one GPU -- a random 1/N of the queries would leave every
+        # brick with 1/N of its queries and the per-rank staging work nearly unchanged (tools/scaling_probe.py)
+        perm = pdist.compact_order(q_all)
+        q_all, mr_all = q_all[perm], mr_all[perm]
     qlo, qhi = pdist.shard_range(Qtot, rank, world)
     q, mr = q_all[qlo:qhi], mr_all[qlo:qhi]
     Q = qhi - qlo
@@ -255,6 +261,15 @@ def main():
         t_ba = timed(ba_step, a.steps, sync)
         extras.update(ba_raw_iter_ms=t_raw * 1e3, nn_wall_ms=t_nn * 1e3, ba_wall_ms=t_ba * 1e3)
         del raw, res_only
+        # ---- what the call sites need: the search bounded by each query's gate (PCD_GATE_BOUNDED_SEARCH) --------
+        # same recorded associations, same field values (tests/test_assoc_gpu.py::test_gate_bounded_search); the
+        # headline above keeps the unbounded exact search for every query
+        def bounded_step():
+            cloud.associate_device(dq, Q, dmr, Q, pcdhip.GATE_MAPPER_LOCAL | pcdhip.GATE_BOUNDED_SEARCH, aout, None, stream)
+        for _ in range(2):
+            bounded_step()
+        t_bnd = timed(bounded_step, a.steps, sync)
+        extras.update(nn_assoc_bounded_ms=t_bnd * 1e3, nn_assoc_bounded_queries_per_sec=Q / t_bnd * world)
         # ---- the drop-in's host path: pinned staging -> H2D -> search + epilogue -> compaction -> D2H of the hits ----
         # (what shim/lidar_hip.h MatchClosestLidarPointsFlat costs after the call site has gathered XYZ into the
         #  staging buffers and before it inserts into its hash maps; both exist in the reference's loops as well)
@@ -279,9 +294,9 @@ def main():
             ka = torch.empty(20_000, dtype=torch.int64, device=dev)
             oa = {k: v[:20_000] for k, v in aout.items()} if Q >= 20_000 else None
             if oa is not None:
-                def a_step():
-                    ca.nn_device(qa, 20_000, ka, pcdhip.NN_AUTO, stream)
-                    ca.associate_device(qa, 20_000, mra, 20_000, pcdhip.GATE_MAPPER_LOCAL, oa, ka, stream)
+                def a_step():   # as the shim calls it: search bounded by the gate, then the epilogue
+                    ca.associate_device(qa, 20_000, mra, 20_000, pcdhip.GATE_MAPPER_LOCAL | pcdhip.GATE_BOUNDED_SEARCH,
+                                        oa, None, stream)
                 for _ in range(3):
                     a_step()
                 torch.cuda.synchronize()

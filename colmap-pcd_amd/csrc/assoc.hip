@@ -178,6 +178,8 @@ __global__ void k_pack_hits(const uint8_t* __restrict__ type, const uint32_t* __
 
 pcd_status nn_query_device_internal(pcd_cloud* c, const double* d_q, uint64_t Q, int algo, uint64_t* d_keys,
                                     hipStream_t s);
+pcd_status nn_query_bounded_internal(pcd_cloud* c, const double* d_q, uint64_t Q, const double* d_max_range,
+                                     uint64_t mr_count, double fixed_range, uint64_t* d_keys, hipStream_t s);
 
 static AssocOut to_dev(const pcd_assoc_out* o) {
   AssocOut a{o->lidar_xyz, o->abcd, o->type, o->dist, o->angle, o->dist2plane, o->nn_idx, o->nn_sqdist};
@@ -194,6 +196,8 @@ pcd_status pcd_associate_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q,
                                 uint64_t max_range_count, int gate_mode, const uint64_t* d_keys_in,
                                 const pcd_assoc_out* d_out, void* stream) {
   PCD_REQUIRE(c && d_out, "null pointer");
+  const bool bounded = (gate_mode & PCD_GATE_BOUNDED_SEARCH) != 0;
+  gate_mode &= ~PCD_GATE_BOUNDED_SEARCH;
   PCD_REQUIRE(gate_mode >= 0 && gate_mode <= 2, "gate_mode");
   PCD_REQUIRE(gate_mode == PCD_GATE_CONTROLLER || (d_max_range && (max_range_count == 1 || max_range_count == Q)),
               "max_range must have 1 or Q entries");
@@ -205,7 +209,12 @@ pcd_status pcd_associate_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q,
   if (!keys) {
     QueryScratch* sc = scratch_of(c);
     PCD_TRY(sc->a_keys.reserve(Q));
-    PCD_TRY(nn_query_device_internal(c, d_q_xyz, Q, PCD_NN_AUTO, sc->a_keys.p, s));
+    if (bounded) {   // controllers/bundle_adjustment.cc:160: dist2point > 2 rejects
+      PCD_TRY(nn_query_bounded_internal(c, d_q_xyz, Q, gate_mode == PCD_GATE_CONTROLLER ? nullptr : d_max_range,
+                                        max_range_count, 2.0, sc->a_keys.p, s));
+    } else {
+      PCD_TRY(nn_query_device_internal(c, d_q_xyz, Q, PCD_NN_AUTO, sc->a_keys.p, s));
+    }
     keys = sc->a_keys.p;
   }
   {
@@ -299,7 +308,9 @@ pcd_status pcd_associate_staged(pcd_cloud* c, uint64_t Q, uint64_t max_range_cou
   if (gate_mode != PCD_GATE_CONTROLLER)
     PCD_HIP_TRY(hipMemcpyAsync(a.a_mr.p, a.h_mr.p, max_range_count * sizeof(double), hipMemcpyHostToDevice, s));
   pcd_assoc_out d{a.a_xyz.p, a.a_abcd.p, a.a_type.p, a.a_dist.p, a.a_angle.p, nullptr, nullptr, nullptr};
-  PCD_TRY(pcd_associate_device(c, a.d_q.p, Q, a.a_mr.p, max_range_count, gate_mode, nullptr, &d, s));
+  // only accepted associations leave this entry point: the search is bounded by the gate
+  PCD_TRY(pcd_associate_device(c, a.d_q.p, Q, a.a_mr.p, max_range_count, gate_mode | PCD_GATE_BOUNDED_SEARCH, nullptr,
+                               &d, s));
   {
     ScopedKernelTimer t("associate_compact", s);
     const auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), HitFlag{a.a_type.p});
@@ -326,8 +337,9 @@ pcd_status pcd_associate_staged(pcd_cloud* c, uint64_t Q, uint64_t max_range_cou
 pcd_status pcd_associate(pcd_cloud* c, const double* q_xyz, uint64_t Q, const double* max_range,
                          uint64_t max_range_count, int gate_mode, const pcd_assoc_out* out) {
   PCD_REQUIRE(c && out, "null pointer");
-  PCD_REQUIRE(gate_mode >= 0 && gate_mode <= 2, "gate_mode");
-  PCD_REQUIRE(gate_mode == PCD_GATE_CONTROLLER || (max_range && (max_range_count == 1 || max_range_count == Q)),
+  const int gate_only = gate_mode & ~PCD_GATE_BOUNDED_SEARCH;
+  PCD_REQUIRE(gate_only >= 0 && gate_only <= 2, "gate_mode");
+  PCD_REQUIRE(gate_only == PCD_GATE_CONTROLLER || (max_range && (max_range_count == 1 || max_range_count == Q)),
               "max_range must have 1 or Q entries");
   if (Q == 0) return PCD_OK;
   PCD_REQUIRE(q_xyz, "null queries");
@@ -340,7 +352,7 @@ pcd_status pcd_associate(pcd_cloud* c, const double* q_xyz, uint64_t Q, const do
   PCD_TRY(a.a_angle.reserve(Q)); PCD_TRY(a.a_d2p.reserve(Q)); PCD_TRY(a.a_type.reserve(Q));
   PCD_TRY(a.d_idx.reserve(Q)); PCD_TRY(a.d_sq.reserve(Q));
   PCD_HIP_TRY(hipMemcpyAsync(a.d_q.p, q_xyz, 3 * Q * sizeof(double), hipMemcpyHostToDevice, s));
-  if (gate_mode != PCD_GATE_CONTROLLER)
+  if (gate_only != PCD_GATE_CONTROLLER)
     PCD_HIP_TRY(hipMemcpyAsync(a.a_mr.p, max_range, max_range_count * sizeof(double), hipMemcpyHostToDevice, s));
   pcd_assoc_out d{a.a_xyz.p, a.a_abcd.p, a.a_type.p, a.a_dist.p, a.a_angle.p, a.a_d2p.p, a.d_idx.p, a.d_sq.p};
   PCD_TRY(pcd_associate_device(c, a.d_q.p, Q, a.a_mr.p, max_range_count, gate_mode, nullptr, &d, s));

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
     if (um) {
       // the wavefront appends to the fallback list inside chunks of kFbChunk slots it reserves with ONE returning
       // atomic each (an atomic per item exposed its latency on every fourth item); unused slots of a chunk keep
-      // the 0xFFFFFFFF the list was filled with and are skipped by k_nn_fallback
+      // the 0xFFFFFFFF the list was filled with; k_fb_compact squeezes them out
       const uint32_t k = (uint32_t)__popcll(um);
       if (k > fb_left) {   // wave-uniform
         uint32_t nb = 0;

@@ -107,11 +107,38 @@ __global__ void k_prepare_refine(const double* __restrict__ q, uint64_t Q, const
   keys[i] = k;
 }
 
-// keys still at kKeyInit mean "nothing found"
+// Gate-bounded search (the association entry points): the three call sites reject an association whose point-to-point
+// distance exceeds max_search_range (mapper) or 2 m (controller), so a query needs no neighbour farther than that.
+// The search starts from key = (bound, index 0xFFFFFFFF) instead of (FLT_MAX, 0): every candidate at or inside the
+// bound beats it, everything beyond is pruned by the same exact float bounds as ever, and a key that still carries
+// the impossible index at the end means "nothing within the gate" (-> PCD_KEY_NONE, type 0, as the reference's gate
+// decides).  bound = float >= R^2 (1 + 1e-5): the float distance of any point that passes the double-precision gate
+// is below it.  NaN range: the reference's `dist > range` is false, nothing is rejected -> unbounded.
+__global__ void k_prepare_bounded(const double* __restrict__ q, uint64_t Q, const double* __restrict__ max_range,
+                                  uint64_t mr_count, double fixed_range, float4* __restrict__ qf4,
+                                  uint64_t* __restrict__ keys) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  float x = (float)q[3 * i], y = (float)q[3 * i + 1], z = (float)q[3 * i + 2];
+  bool ok = isfinite(x) && isfinite(y) && isfinite(z);
+  qf4[i] = make_float4(x, y, z, ok ? 1.f : 0.f);
+  const double R = max_range ? max_range[mr_count == 1 ? 0 : i] : fixed_range;
+  uint64_t k = kKeyInit;
+  if (R == R) {   // not NaN
+    const double b = R < 0.0 ? 0.0 : R * R * (1.0 + 1e-5);
+    float bf = (float)b;
+    if ((double)bf < b) bf = nextafterf(bf, INFINITY);
+    if (bf < FLT_MAX) k = ((uint64_t)__float_as_uint(bf) << 32) | 0xFFFFFFFFull;
+  }
+  keys[i] = k;
+}
+
+// keys still at their initial value (kKeyInit, or a bound with the impossible index) mean "nothing found"
 __global__ void k_finalize_keys(uint64_t* __restrict__ keys, uint64_t Q) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= Q) return;
-  if (keys[i] == kKeyInit) keys[i] = PCD_KEY_NONE;
+  const uint64_t k = keys[i];
+  if (k == kKeyInit || (uint32_t)k == 0xFFFFFFFFu) keys[i] = PCD_KEY_NONE;
 }
 
 __global__ void k_unpack_keys(const uint64_t* __restrict__ keys, uint64_t Q, uint32_t* __restrict__ idx,
@@ -180,49 +207,134 @@ __global__ void k_brick_keys(const float4* __restrict__ qf4, uint64_t Q, GridPar
   vals[i] = (uint32_t)i;
 }
 
-// scan inputs computed on the fly from the sorted keys
-struct RunHeadPos {   // j -> j if a run of equal keys starts at j, else 0  (inclusive max-scan = start of j's run)
-  const uint32_t* keys;
-  __device__ uint32_t operator()(uint32_t j) const { return (j > 0 && keys[j - 1] != keys[j]) ? j : 0u; }
-};
+// ---- work items from the sorted keys: two launches (count per tile, then offsets + emit) -------------------------
+// A work item starts at sorted position j when its key is a brick id and (j - start of j's run of equal keys) is a
+// multiple of G.  A tile = 1024 consecutive positions handled by one workgroup (4 per thread).
+constexpr uint32_t kBkTile = 1024;
+
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) { return ~wave_scan_min_u32(~v); }   // inclusive
+
+// per thread: keys of its 4 positions, start of each position's run, item flags; returns the tile's item count
+// through *tile_items (valid in every thread).  s_* : LDS scratch of the workgroup.
 template <int G>
-struct ItemFlag {     // j -> 1 if a work item starts at j
-  const uint32_t* keys;
-  const uint32_t* run_start;
-  uint32_t nbricks;
-  __device__ uint32_t operator()(uint32_t j) const {
-    return (keys[j] < nbricks && ((j - run_start[j]) % G) == 0u) ? 1u : 0u;
+__device__ __forceinline__ void brick_tile(const uint32_t* __restrict__ keys, uint32_t Q, uint32_t nbricks,
+                                           uint32_t tile, uint32_t (&key)[4], uint32_t (&excl_items)[4],
+                                           bool (&flag)[4], uint32_t* tile_items, uint32_t* s_wave /*[8]*/,
+                                           uint32_t* s_left /*[1]*/) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t j0 = tile * kBkTile + tid * 4;
+  const uint32_t tile_start = tile * kBkTile;
+  uint32_t prev = j0 > 0 && j0 - 1 < Q ? keys[j0 - 1] : 0xFFFFFFFFu;
+  uint32_t hp[4];   // position of the run head at or before each element, 0 = none seen yet in this thread
+  uint32_t run = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t j = j0 + k;
+    key[k] = j < Q ? keys[j] : 0xFFFFFFFFu;
+    const bool head = j < Q && (j == 0 || key[k] != prev);
+    run = head ? j : run;
+    hp[k] = run;
+    prev = key[k];
   }
-};
+  // run start carried in from the threads to the left (max-scan of the last head position per thread)
+  const uint32_t inc = wave_scan_max_u32(run);
+  if (lane == 63) s_wave[wave] = inc;
+  // the run that crosses the tile's left edge starts before the tile: first position with that key (sorted array)
+  if (tid == 0) {
+    uint32_t left = tile_start;
+    if (tile_start > 0 && tile_start < Q && keys[tile_start - 1] == keys[tile_start]) {
+      const uint32_t k0 = keys[tile_start];
+      uint32_t lo = 0, hi = tile_start;   // first index in [0, tile_start] with keys[idx] >= k0 (== k0)
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < k0) lo = mid + 1; else hi = mid; }
+      left = lo;
+    }
+    s_left[0] = left;
+  }
+  __syncthreads();
+  uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)inc, 0);   // placeholder, replaced below
+  {
+    uint32_t up = __shfl_up(inc, 1);
+    carry = lane == 0 ? 0u : up;            // exclusive within the wave
+    for (uint32_t w = 0; w < wave; ++w) carry = max(carry, s_wave[w]);
+  }
+  const uint32_t left = s_left[0];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t j = j0 + k;
+    uint32_t rs = max(hp[k], carry);
+    // no head at or before j inside this tile (rs == 0 cannot be a real head unless tile 0, where left == 0 too)
+    if (rs == 0 || rs < tile_start) rs = left;
+    flag[k] = j < Q && key[k] < nbricks && ((j - rs) % (uint32_t)G) == 0u;
+    excl_items[k] = cnt;
+    cnt += flag[k] ? 1u : 0u;
+  }
+  // exclusive sum-scan of the per-thread item counts over the workgroup
+  const uint32_t sinc = wave_scan_add_u32(cnt);
+  __syncthreads();                        // s_wave is reused
+  if (lane == 63) s_wave[wave] = sinc;
+  __syncthreads();
+  uint32_t base = sinc - cnt, total = 0;
+  for (uint32_t w = 0; w < 4; ++w) { if (w < wave) base += s_wave[w]; total += s_wave[w]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) excl_items[k] += base;
+  *tile_items = total;
+}
 
 template <int G>
-__global__ void k_brick_emit(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                             const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ item_idx,
-                             const float4* __restrict__ qf4, const uint64_t* __restrict__ keys_in, uint32_t Q,
-                             uint32_t nbricks, uint32_t nb0, uint32_t nb1, uint4* __restrict__ items,
-                             float4* __restrict__ qsorted, uint64_t* __restrict__ ksorted,
-                             uint32_t* __restrict__ fb_list, NnCounters* __restrict__ ctr) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= Q) return;
-  const uint32_t key = keys[j], v = vals[j];
-  const bool is_item = key < nbricks && ((j - run_start[j]) % G) == 0u;
-  if (key < nbricks) {
-    float4 q = qf4[v];
-    q.w = __uint_as_float(v);          // brick-sorted query record {x, y, z, bits(query id)}
-    qsorted[j] = q;
-    // the key the query came with, in the same order (a plain query comes with kKeyInit: no gather)
-    ksorted[j] = keys_in ? keys_in[v] : kKeyInit;
-    if (is_item) {
-      uint32_t cnt = 1;
-      while (cnt < (uint32_t)G && j + cnt < Q && keys[j + cnt] == key) ++cnt;
-      // item record {first query, brick x, brick y, brick z | count << 28}: the brick kernel needs no divisions
-      const uint32_t bx = key % nb0, by = (key / nb0) % nb1, bz = key / (nb0 * nb1);
-      items[item_idx[j]] = make_uint4(j, bx, by, bz | (cnt << 28));
+__global__ __launch_bounds__(256) void k_brick_tile_count(const uint32_t* __restrict__ keys, uint32_t Q, uint32_t nbricks,
+                                                          uint32_t* __restrict__ tile_items) {
+  __shared__ uint32_t s_wave[8], s_left[1];
+  uint32_t key[4], ex[4], total;
+  bool flag[4];
+  brick_tile<G>(keys, Q, nbricks, blockIdx.x, key, ex, flag, &total, s_wave, s_left);
+  if (threadIdx.x == 0) tile_items[blockIdx.x] = total;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_brick_emit(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                    const uint32_t* __restrict__ tile_items, const float4* __restrict__ qf4,
+                                                    const uint64_t* __restrict__ keys_in, uint32_t Q, uint32_t nbricks,
+                                                    uint32_t nb0, uint32_t nb1, uint4* __restrict__ items,
+                                                    float4* __restrict__ qsorted, uint64_t* __restrict__ ksorted,
+                                                    uint32_t* __restrict__ fb_list, NnCounters* __restrict__ ctr) {
+  __shared__ uint32_t s_wave[8], s_left[1], s_off[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // items of the tiles to the left: fixed-order strided sums (few hundred values)
+  uint32_t part = 0;
+  for (uint32_t t = tid; t < blockIdx.x; t += 256) part += tile_items[t];
+  part = wave_scan_add_u32(part);
+  if (lane == 63) s_off[wave] = part;
+  __syncthreads();
+  const uint32_t tile_off = s_off[0] + s_off[1] + s_off[2] + s_off[3];
+  __syncthreads();
+  uint32_t key[4], ex[4], total;
+  bool flag[4];
+  brick_tile<G>(keys, Q, nbricks, blockIdx.x, key, ex, flag, &total, s_wave, s_left);
+  const uint32_t j0 = blockIdx.x * kBkTile + tid * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t j = j0 + k;
+    if (j >= Q) break;
+    const uint32_t v = vals[j];
+    if (key[k] < nbricks) {
+      float4 q = qf4[v];
+      q.w = __uint_as_float(v);          // brick-sorted query record {x, y, z, bits(query id)}
+      qsorted[j] = q;
+      // the key the query came with, in the same order (a plain query comes with kKeyInit: no gather)
+      ksorted[j] = keys_in ? keys_in[v] : kKeyInit;
+      if (flag[k]) {
+        uint32_t cnt = 1;
+        while (cnt < (uint32_t)G && j + cnt < Q && keys[j + cnt] == key[k]) ++cnt;
+        // item record {first query, brick x, brick y, brick z | count << 28}: the brick kernel needs no divisions
+        const uint32_t bx = key[k] % nb0, by = (key[k] / nb0) % nb1, bz = key[k] / (nb0 * nb1);
+        items[tile_off + ex[k]] = make_uint4(j, bx, by, bz | (cnt << 28));
+      }
+    } else if (key[k] == nbricks) {
+      fb_list[atomicAdd(&ctr->fb_count, 1u)] = v;   // outside the grid: straight to the exact fallback
     }
-  } else if (key == nbricks) {
-    fb_list[atomicAdd(&ctr->fb_count, 1u)] = v;   // outside the grid: straight to the exact fallback
   }
-  if (j == Q - 1) ctr->nitems = item_idx[j] + (is_item ? 1u : 0u);
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) ctr->nitems = tile_off + total;
 }
 
 // ------------------------------------------------------------ brick kernel ---
@@ -257,6 +369,23 @@ __device__ __forceinline__ double proven_bound(const GridParams& g, float qx, fl
 #include "brick_kernel.h"
 namespace pcd {
 
+
+// The brick kernel fills the fallback list in per-wavefront chunks (brick_kernel.h kFbChunk); the unused slots of
+// the chunks keep 0xFFFFFFFF.  One pass squeezes them out (wave-aggregated atomics: the order of the dense list is
+// not deterministic, the per-query results do not depend on it) so that k_nn_fallback gets an evenly filled list.
+__global__ void k_fb_compact(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count_ptr,
+                             uint32_t* __restrict__ dense, uint32_t* __restrict__ dense_count) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t v = e < *count_ptr ? list[e] : 0xFFFFFFFFu;
+  const bool keep = v != 0xFFFFFFFFu;
+  const unsigned long long m = __ballot(keep);
+  if (m == 0) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(dense_count, (uint32_t)__popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1);
+  if (keep) dense[base + __popcll(m & ((1ull << lane) - 1))] = v;
+}
 
 // --------------------------------------------------------- exact fallback ---
 // scan the point range [s,e): lanes stride over it
@@ -293,16 +422,8 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
   const int top = py.nlev - 1;  // >= 1
   const int ci = lane & 3, cj = (lane >> 2) & 3, ck = lane >> 4;
   unsigned long long st_pts = 0, st_q = 0;
-  // The list is filled in chunks of 64 slots (brick_kernel.h kFbChunk), each used from its first slot on, the rest
-  // left at 0xFFFFFFFF.  Wavefront w takes every nwaves-th entry of the TRANSPOSED order (slot-in-chunk major):
-  // taking every nwaves-th entry of the list itself would give a wavefront the same slot of every chunk, and the
-  // low slots -- always used -- 2-3x the work of the high ones.
-  const uint32_t nch = (count + 63u) / 64u;
-  for (uint32_t t = blockIdx.x * 4 + wave; t < (list ? nch * 64u : count); t += nwaves) {
-    const uint32_t e = list ? (t % nch) * 64u + t / nch : t;
-    if (e >= count) continue;
+  for (uint32_t e = blockIdx.x * 4 + wave; e < count; e += nwaves) {
     const uint32_t qi = list ? list[e] : e;
-    if (qi == 0xFFFFFFFFu) continue;   // unused slot of a wavefront's chunk
     const float4 q = qf4[qi];
     if (q.w == 0.f) continue;  // not finite: stays "not found"
     const float qx = q.x, qy = q.y, qz = q.z;
@@ -424,8 +545,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   PCD_HIP_TRY(hipMemsetAsync(sc->fb_list.p, 0xFF, fb_cap * sizeof(uint32_t), s));
   PCD_TRY(sc->bk_keys.reserve(2 * Q));
   PCD_TRY(sc->bk_vals.reserve(2 * Q));
-  PCD_TRY(sc->bk_run.reserve(Q));
-  PCD_TRY(sc->bk_item.reserve(Q));
+  PCD_TRY(sc->bk_item.reserve(div_up(Q, kBkTile) + 1));
   PCD_TRY(sc->items.reserve(Q + 1));
   PCD_TRY(sc->counters.reserve(1));
   PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
@@ -444,18 +564,11 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     PCD_HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tb, k0, k1, v0, v1, (unsigned)Q, 0u, end_bit, s));
     PCD_TRY(sc->tmp.reserve(tb));
     PCD_HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(sc->tmp.p, tb, k0, k1, v0, v1, (unsigned)Q, 0u, end_bit, s));
-    const auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), RunHeadPos{k1});
-    PCD_HIP_TRY(rocprim::inclusive_scan(nullptr, tb, heads, sc->bk_run.p, (size_t)Q, rocprim::maximum<uint32_t>(), s));
-    PCD_TRY(sc->tmp.reserve(tb));
-    PCD_HIP_TRY(rocprim::inclusive_scan(sc->tmp.p, tb, heads, sc->bk_run.p, (size_t)Q, rocprim::maximum<uint32_t>(), s));
-    const auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u),
-                                                        ItemFlag<G>{k1, sc->bk_run.p, b.nbricks});
-    PCD_HIP_TRY(rocprim::exclusive_scan(nullptr, tb, flags, sc->bk_item.p, 0u, (size_t)Q, rocprim::plus<uint32_t>(), s));
-    PCD_TRY(sc->tmp.reserve(tb));
-    PCD_HIP_TRY(rocprim::exclusive_scan(sc->tmp.p, tb, flags, sc->bk_item.p, 0u, (size_t)Q, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL(k_brick_emit<G>, dim3(div_up(Q, 256)), dim3(256), 0, s, k1, v1, sc->bk_run.p, sc->bk_item.p,
-                       sc->qf4.p, refine ? d_keys : (const uint64_t*)nullptr, (uint32_t)Q, b.nbricks, (uint32_t)b.nb[0], (uint32_t)b.nb[1], sc->items.p,
-                       sc->qsorted.p, sc->ksorted.p, sc->fb_list.p, sc->counters.p);
+    const unsigned ntiles = div_up(Q, kBkTile);
+    hipLaunchKernelGGL(k_brick_tile_count<G>, dim3(ntiles), dim3(256), 0, s, k1, (uint32_t)Q, b.nbricks, sc->bk_item.p);
+    hipLaunchKernelGGL(k_brick_emit<G>, dim3(ntiles), dim3(256), 0, s, k1, v1, sc->bk_item.p, sc->qf4.p,
+                       refine ? d_keys : (const uint64_t*)nullptr, (uint32_t)Q, b.nbricks, (uint32_t)b.nb[0],
+                       (uint32_t)b.nb[1], sc->items.p, sc->qsorted.p, sc->ksorted.p, sc->fb_list.p, sc->counters.p);
   }
   {
     ScopedKernelTimer t("nn_brick", s);
@@ -465,23 +578,36 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   }
   {
     ScopedKernelTimer t("nn_fallback", s);
+    PCD_TRY(sc->fb_dense.reserve(Q));
+    hipLaunchKernelGGL(k_fb_compact, dim3(div_up(fb_cap, 256)), dim3(256), 0, s, sc->fb_list.p,
+                       &sc->counters.p->fb_count, sc->fb_dense.p, &sc->counters.p->pad[0]);
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), 256 * 8);
     hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, g, c->pyr, c->sorted.p, c->cell_start.p,
-                       c->blk_aabb.p, sc->qf4.p, sc->fb_list.p, &sc->counters.p->fb_count, 0u, d_keys,
+                       c->blk_aabb.p, sc->qf4.p, sc->fb_dense.p, &sc->counters.p->pad[0], 0u, d_keys,
                        sc->counters.p, g_collect_stats);
   }
   return PCD_OK;
 }
 
+struct NnBound {        // gate-bounded search: per-query / scalar ranges, or one fixed range; count == 0: unbounded
+  const double* d_max_range = nullptr;
+  uint64_t count = 0;
+  double fixed = 0.0;
+};
+
 static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int algo, uint64_t* d_keys,
-                            hipStream_t s, bool refine = false, const uint8_t* d_skip = nullptr) {
+                            hipStream_t s, bool refine = false, const uint8_t* d_skip = nullptr,
+                            const NnBound* bound = nullptr) {
   QueryScratch* sc = scratch_of(c);
   if (Q == 0) return PCD_OK;
   PCD_REQUIRE(Q < 0xFFFFFFF0ull, "more than 2^32 queries in one call");
   PCD_TRY(sc->qf4.reserve(Q));
   {
     ScopedKernelTimer t("nn_prepare", s);
-    if (refine)
+    if (bound)
+      hipLaunchKernelGGL(k_prepare_bounded, dim3(div_up(Q, 256)), dim3(256), 0, s, d_q, Q, bound->d_max_range,
+                         bound->count, bound->fixed, sc->qf4.p, d_keys);
+    else if (refine)
       hipLaunchKernelGGL(k_prepare_refine, dim3(div_up(Q, 256)), dim3(256), 0, s, d_q, Q, d_skip, c->bb_lo[0],
                          c->bb_lo[1], c->bb_lo[2], c->bb_hi[0], c->bb_hi[1], c->bb_hi[2], sc->qf4.p, d_keys);
     else
@@ -507,7 +633,7 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
                          c->blk_aabb.p, sc->qf4.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)Q,
                          d_keys, sc->counters.p, g_collect_stats);
     } else if (algo == PCD_NN_AUTO || algo == PCD_NN_GRID) {
-      PCD_TRY(run_grid<8>(c, sc, Q, d_keys, s, refine));
+      PCD_TRY(run_grid<8>(c, sc, Q, d_keys, s, refine || bound != nullptr));   // incoming keys matter: carry them
     } else {
       set_error("unknown nn algo %d", algo);
       return PCD_ERR_INVALID;
@@ -524,6 +650,13 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
 pcd_status nn_query_device_internal(pcd_cloud* c, const double* d_q, uint64_t Q, int algo, uint64_t* d_keys,
                                     hipStream_t s) {
   return nn_device(c, d_q, Q, algo, d_keys, s);
+}
+// bounded by the association gate: d_max_range (1 or Q entries) or, when NULL, fixed_range
+pcd_status nn_query_bounded_internal(pcd_cloud* c, const double* d_q, uint64_t Q, const double* d_max_range,
+                                     uint64_t mr_count, double fixed_range, uint64_t* d_keys, hipStream_t s) {
+  NnBound b;
+  b.d_max_range = d_max_range; b.count = mr_count; b.fixed = fixed_range;
+  return nn_device(c, d_q, Q, PCD_NN_AUTO, d_keys, s, false, nullptr, &b);
 }
 
 }  // namespace pcd

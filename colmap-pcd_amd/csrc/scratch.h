@@ -7,18 +7,18 @@ namespace pcd {
 struct NnCounters {
   unsigned long long brick_groups, staged_points, fallback_queries, fallback_points, pair_evals;
   unsigned int nitems, fb_count;
-  unsigned int pad[2];
+  unsigned int pad[2];   // pad[0] = length of the squeezed fallback list
 };
 
 struct QueryScratch {
   DevBuf<float4> qf4;          // (float)query, w = 1 valid / 0 not finite
   DevBuf<uint64_t> keys;       // host-API result keys
   DevBuf<uint32_t> bk_keys, bk_vals;   // (brick id, query id) pairs, unsorted | sorted halves
-  DevBuf<uint32_t> bk_run, bk_item;    // per sorted position: start of its run, index of the item starting there
+  DevBuf<uint32_t> bk_item;            // work items per tile of 1024 sorted positions
   DevBuf<float4> qsorted;      // brick-sorted query records {x,y,z,bits(query id)}
   DevBuf<uint64_t> ksorted;    // their incoming keys, same order
   DevBuf<uint4> items;         // {first query, brick x, brick y, brick z | count << 28}
-  DevBuf<uint32_t> fb_list;
+  DevBuf<uint32_t> fb_list, fb_dense;   // fallback list as the brick kernel fills it (chunked) / squeezed
   DevBuf<NnCounters> counters;
   DevBuf<char> tmp;
   DevBuf<double> d_q;          // staging of host queries

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("PCDHIP_LIB", os.path.join(_ROOT, "libpcdhip.so"))   #
 PCD_OK, PCD_ERR_INVALID, PCD_ERR_NO_DEVICE, PCD_ERR_HIP, PCD_ERR_OOM, PCD_ERR_UNSUPPORTED = range(6)
 NN_AUTO, NN_BRUTEFORCE, NN_FALLBACK_ONLY, NN_GRID = 0, 1, 2, 3
 GATE_MAPPER_LOCAL, GATE_MAPPER_GLOBAL, GATE_CONTROLLER = 0, 1, 2
+GATE_BOUNDED_SEARCH = 0x100   # OR-ed into a gate mode: search bounded by the gate (pcdhip.h)
 LIDAR_NONE, LIDAR_ICP, LIDAR_ICP_GROUND = 0, 1, 2
 LOSS_TRIVIAL, LOSS_SOFT_L1, LOSS_CAUCHY = 0, 1, 2
 LAYOUT_XYZ_NRM, LAYOUT_AOS32 = 0, 1
@@ -286,7 +287,7 @@ class Cloud:
         ao = AssocOut(*[_vp(out[k]) for k in ("lidar_xyz", "abcd", "type", "dist", "angle", "dist2plane",
                                                "nn_idx", "nn_sqdist")])
         mr, mrc = None, 0
-        if gate_mode != GATE_CONTROLLER:
+        if (gate_mode & 0xFF) != GATE_CONTROLLER:
             mr = np.ascontiguousarray(np.atleast_1d(np.asarray(max_range, np.float64)))
             mrc = mr.shape[0]
         _check(lib().pcd_associate(self._h, _vp(q), Q, _vp(mr), mrc, gate_mode, C.byref(ao)))

@@ -147,6 +147,13 @@ pcd_status pcd_nn_refine_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q,
  * --------------------------------------------------------------------- */
 typedef enum { PCD_GATE_MAPPER_LOCAL = 0, PCD_GATE_MAPPER_GLOBAL = 1, PCD_GATE_CONTROLLER = 2 } pcd_gate_mode;
 typedef enum { PCD_LIDAR_NONE = 0, PCD_LIDAR_ICP = 1, PCD_LIDAR_ICP_GROUND = 2 } pcd_lidar_type;
+/* OR-ed into gate_mode: bound the search by the gate.  All three call sites drop an association whose
+ * point-to-point distance exceeds max_range (mapper) / 2 m (controller), so no neighbour beyond that distance can be
+ * recorded; with this flag the search prunes there (exact inside the bound), the set of recorded associations and
+ * every field of their rows are identical, and rows with type 0 carry zeros / 0xFFFFFFFF instead of the rejected
+ * winner.  Ignored when keys are passed in.  pcd_associate_staged always searches this way (it returns only the
+ * recorded associations); pcd_nn_query* is never bounded. */
+#define PCD_GATE_BOUNDED_SEARCH 0x100
 
 typedef struct {
   double* lidar_xyz;   /* [Q][3] LidarPoint::LidarXYZ()  (winner position as doubles)        */

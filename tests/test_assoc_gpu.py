@@ -171,3 +171,38 @@ def test_staged_host_path(gpu, oracle, mode):
     sq[:] = far; smr[:] = 1.0
     assert len(c.associate_staged(10, 10, 0)) == 0   # nothing accepted
     c.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gate_bounded_search(gpu, oracle, mode):
+    """PCD_GATE_BOUNDED_SEARCH: the search prunes at the gate radius.  The recorded associations (type != 0) and every
+    field of their rows must be identical to the unbounded search + gate (= the oracle = the reference's loops);
+    rows the gate rejects carry type 0.  Includes NaN / negative / huge ranges, queries far outside the cloud, and
+    both the grid path (large batch) and the one-launch path (small batch)."""
+    xyz, nrm = synth.cloud_planes(120000, seed=20240601, patches=24)
+    nrm[::97] = 0.0
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    for Q, seed in ((90000, 5), (3000, 6)):
+        q = synth.queries(xyz, Q, seed=seed, outlier_frac=0.15)
+        q[:50] = (np.random.default_rng(seed).random((50, 3)) - 0.5) * 800.0     # far outside the grid
+        mr = synth.max_range_schedule(Q, seed=seed)
+        mr[100:110] = np.nan          # `dist > NaN` is false: nothing rejected -> unbounded for these
+        mr[110:120] = -1.0            # everything rejected
+        mr[120:130] = 1e30            # no gate at all
+        mr[130:140] = 0.0
+        full = c.associate(q, None if mode == 2 else mr, mode)
+        bnd = c.associate(q, None if mode == 2 else mr, mode | gpu.GATE_BOUNDED_SEARCH)
+        assert np.array_equal(bnd["type"], full["type"])
+        acc = full["type"] != 0
+        assert 0.3 * Q < acc.sum() < Q
+        for k in ("lidar_xyz", "abcd", "dist", "angle", "dist2plane", "nn_idx", "nn_sqdist"):
+            assert np.array_equal(bnd[k][acc], full[k][acc]), k
+        # against the oracle as well (unbounded brute force + gate)
+        idx, sq, found = oracle.nn_bruteforce(xyz, q)
+        out6, ok = oracle.search_nearest_neibor(xyz, nrm, idx, found)
+        _, typ, _, _, _ = oracle.associate(q, out6, ok, None if mode == 2 else mr, mode)
+        assert np.array_equal(bnd["type"], typ)
+        if mode != 2:
+            assert bnd["type"][100:110].any() or not typ[100:110].any()
+            assert not bnd["type"][110:120].any()
+    c.close()
