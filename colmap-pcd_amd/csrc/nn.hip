@@ -556,11 +556,11 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     unsigned end_bit = 1;
     while (end_bit < 32 && ((uint64_t)1 << end_bit) <= (uint64_t)b.nbricks + 1) ++end_bit;
     size_t tb = 0;
-    // rocPRIM's default takes its merge sort (log2(Q / block) launches) up to 2^20 items: Onesweep above 32 k
+    // rocPRIM's default takes its merge sort (log2(Q / block) launches) up to 2^20 items: Onesweep above 256 k (below that its ~25 us per digit pass cost more than the merge passes)
 // (Onesweep with 10-12-bit digits -- two passes over the 23-bit brick ids instead of three -- does not fit:
     //  rocPRIM's block ranking then needs 192 KiB - 2 MiB of LDS)
     using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                               rocprim::default_config, 32768>;
+                                               rocprim::default_config, 262144>;
     PCD_HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tb, k0, k1, v0, v1, (unsigned)Q, 0u, end_bit, s));
     PCD_TRY(sc->tmp.reserve(tb));
     PCD_HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(sc->tmp.p, tb, k0, k1, v0, v1, (unsigned)Q, 0u, end_bit, s));
