@@ -50,6 +50,13 @@ __device__ __forceinline__ void lds_dma16(const float4* gsrc, float4* lds_wave_b
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// the same with a compile-time byte offset on the source address (instruction k of a 4-slot group)
+template <int OFF>
+__device__ __forceinline__ void lds_dma16_off(const float4* gsrc, float4* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, OFF, 0);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
@@ -234,15 +241,17 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
     item_end = nitems;
   }
   if (item >= item_end) return;
-  uint4 it0 = items[item];
+  // item records through uniform (scalar) indices: they land in SGPRs instead of 12 VGPRs
+#define PCD_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+  uint4 it0 = items[PCD_UNI(item)];
   BrickMeta m0 = brick_load_meta(g, b, it0, qsorted, ksorted, cell_start);
-  uint4 it1 = items[min(item + stride, item_end - 1)];
+  uint4 it1 = items[PCD_UNI(min(item + stride, item_end - 1))];
 
   for (; item < item_end; item += stride) {
     // ---- prefetch: metadata of the next group, item record of the one after ----
     // (unconditional, clamped to the last item: see brick_load_meta)
     const BrickMeta m1 = brick_load_meta(g, b, it1, qsorted, ksorted, cell_start);
-    const uint4 it2 = items[min(item + 2 * stride, item_end - 1)];
+    const uint4 it2 = items[PCD_UNI(min(item + 2 * stride, item_end - 1))];
 
     // ---- current group ----
     const uint32_t cnt = (uint32_t)item_count(it0);
@@ -256,11 +265,26 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
     }
     int c0[3], c1[3];
     brick_region(g, b, it0, c0, c1);
+    // ---- slot -> source index ------------------------------------------------------------------
+    // The concatenation of the region's ranges is addressed in GROUPS of 4 consecutive slots: every range is
+    // padded to a multiple of 4 slots (the <= 3 padding slots read the records that follow the range in memory:
+    // real cloud points of the neighbouring cells, harmless extra candidates; the `sorted` buffer ends with 4
+    // spare records), so the 4 slots of a group are 4 consecutive records.  Lane l of tile t takes group
+    // t * 64 + l: ONE source address per lane per tile, and the tile's 4 DMA instructions are that address +
+    // 0 / 16 / 32 / 48 bytes (instruction k fills LDS slot k * 64 + l -- a permutation of the tile, and the
+    // compare does not care about the order).  The range of a group is found with one compare + select per
+    // range start (the starts are wave-uniform): no per-window tables, no v_readlane inside the tile loop,
+    // any number of range starts inside a tile.  Round 1-2a computed an address per 64-slot DMA window (three
+    // v_readlane + ~10 VALU each, plus a generic path for windows with two starts); timing-only ablations put
+    // that address generation at 0.34 ms of the kernel's 0.84.
     uint32_t T;
     const uint32_t len = m0.e - m0.s;
-    // lane r: start of range r in the concatenation (lanes >= nrows: T) and source - start
-    const uint32_t off = wave_excl_scan_u32(len, T);
+    const uint32_t len4 = (len + 3u) & ~3u;
+    // lane r: start of range r in the padded concatenation (lanes >= nrows: T) and source - start
+    const uint32_t off = wave_excl_scan_u32(len4, T);
     const uint32_t delta = m0.s - off;
+    const int yq0 = c0[1] >> 1, zq0 = c0[2] >> 1;
+    const int nrows = (((c1[1] + 1) >> 1) - yq0) * (((c1[2] + 1) >> 1) - zq0);   // wave-uniform, <= 64
 
     double best[G];   // packed keys, minimised as doubles (compare_point)
 #pragma unroll
@@ -268,115 +292,93 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
 
     if (T > 0 && !(flags & kAblateTiles)) {
       const int ntiles = (int)((T + kTile - 1) / kTile);
-      // ---- slot -> source index ------------------------------------------------------------------
-      // Window w = the 64 slots of one DMA instruction.  Lane w of (w_d0, w_ob, w_d1) describes window w:
-      // the source delta at its first slot, the first range start inside it (or ~0) and the delta from
-      // there on.  Built once per item with lanes = windows: `cur` = number of range starts <= the
-      // window's first slot (the starts are non-decreasing), then three cross-lane gathers.  A window
-      // with two or more starts inside, or more than 64 windows (T > 4096), sends the whole item down
-      // the generic path below; with ~110-point ranges that is rare.
-      const uint32_t wslot = min((uint32_t)lane * 64u, T - 1);
-      uint32_t curw = 0;
-      for (int r = 1; r < 64; ++r) {
-        const uint32_t o_r = (uint32_t)__builtin_amdgcn_readlane((int)off, r);
-        if (o_r >= T) break;   // wave-uniform: lanes past the last non-empty range hold T
-        curw += o_r <= wslot ? 1u : 0u;
-      }
-      const int a1 = (int)min(curw + 1u, 63u) * 4, a2 = (int)min(curw + 2u, 63u) * 4;
-      const uint32_t w_d0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)curw * 4, (int)delta);
-      uint32_t w_ob = (uint32_t)__builtin_amdgcn_ds_bpermute(a1, (int)off);
-      const uint32_t w_d1 = (uint32_t)__builtin_amdgcn_ds_bpermute(a1, (int)delta);
-      const uint32_t w_o2 = (uint32_t)__builtin_amdgcn_ds_bpermute(a2, (int)off);
-      const bool in_use = (uint32_t)lane * 64u < T;
-      const bool two_starts = in_use && a2 != a1 && w_o2 <= wslot + 63u && w_o2 < T;
-      if (!(w_ob <= wslot + 63u && w_ob < T)) w_ob = 0xFFFFFFFFu;
-      const bool fast = __ballot(two_starts) == 0ull && T <= 4096u;
-
       const char* __restrict__ src_bytes = reinterpret_cast<const char*>(sorted);
-      int cur = 0;   // generic path: largest range index whose start is <= the first slot of the window
-      // issue the 4 DMAs of tile t (always exactly 4 instructions: slots past T re-read point T-1, which
+      // issue the 4 DMAs of tile t (always exactly 4 instructions: groups past T re-read the last group, which
       // cannot change a minimum -- the compare needs no tail mask)
-      auto issue_tile = [&](int t, auto fast_tag) {
+      // range starts / deltas of the first 9 ranges (all of them for B = R = 2) once per item, wave-uniform;
+      // lanes >= nrows hold start = T, which no group reaches.  Scalars, not arrays: captured arrays stay in
+      // memory and hipcc then turns the select chain into an indexed scratch load inside the tile loop.
+      // starts stay in SGPRs (a VOPC compare may read one), deltas are copied to VGPRs (v_cndmask cannot read an
+      // SGPR next to VCC on gfx9): 8 live VGPRs per item instead of 12 v_readlane + hazards per tile
+#define PCD_RL(v, r) ((uint32_t)__builtin_amdgcn_readlane((int)(v), r))
+      const uint32_t o1 = PCD_RL(off, 1), o2 = PCD_RL(off, 2), o3 = PCD_RL(off, 3), o4 = PCD_RL(off, 4),
+                     o5 = PCD_RL(off, 5), o6 = PCD_RL(off, 6), o7 = PCD_RL(off, 7), o8 = PCD_RL(off, 8);
+      uint32_t d0, d1, d2, d3, d4, d5, d6, d7, d8;
+#define PCD_VB(dst, r) asm volatile("v_mov_b32 %0, %1" : "=v"(dst) : "s"(PCD_RL(delta, r)))
+      PCD_VB(d0, 0); PCD_VB(d1, 1); PCD_VB(d2, 2); PCD_VB(d3, 3); PCD_VB(d4, 4); PCD_VB(d5, 5); PCD_VB(d6, 6);
+      PCD_VB(d7, 7); PCD_VB(d8, 8);
+#undef PCD_VB
+#undef PCD_RL
+      auto issue_tile = [&](int t) {
         float4* buf = s_tile[wave][t & 1];
-#pragma unroll
-        for (int k = 0; k < kTile / 64; ++k) {
-          const uint32_t base_raw = (uint32_t)t * kTile + k * 64;
-          uint32_t idx;
-          if constexpr (decltype(fast_tag)::value) {
-            const int w = (int)(base_raw >> 6);   // < 64 on this path; windows past T hold the entry of T-1
-            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)w_d0, w);
-            const uint32_t ob = (uint32_t)__builtin_amdgcn_readlane((int)w_ob, w);
-            const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)w_d1, w);
-            const uint32_t gi = min(base_raw + (uint32_t)lane, T - 1);
-            idx = gi + (gi >= ob ? d1 : d0);
-          } else {
-            const uint32_t base = min(base_raw, T - 1);
-            const uint32_t gi = min(base + (uint32_t)lane, T - 1);
-            while (cur < 63 && (uint32_t)__builtin_amdgcn_readlane((int)off, cur + 1) <= base) ++cur;
-            uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)delta, cur);
-            // range starts inside the window (empty ranges share a start: the last one wins)
-            for (int j = cur + 1; j < 64; ++j) {
-              const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
-              if (oj > base + 63 || oj >= T) break;
-              const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)delta, j);
-              dl = gi >= oj ? dj : dl;
-            }
-            idx = gi + dl;
-          }
-          // uniform base + byte offset (64-bit: a cloud may exceed 2^28 points = 4 GiB of records)
-          const float4* gp = reinterpret_cast<const float4*>(src_bytes + ((uint64_t)idx << 4));
-          if (!(flags & kAblateNoDma)) lds_dma16(gp, buf + k * 64);
-          else asm volatile("" ::"v"(gp));
+        const uint32_t s4 = min((uint32_t)t * kTile + 4u * (uint32_t)lane, T - 4u);
+        uint32_t dl = d0;   // empty ranges share their start with the next one: the last one wins
+#define PCD_SEL(o, d) asm("v_cmp_le_u32_e32 vcc, %2, %1\n\tv_cndmask_b32_e32 %0, %0, %3, vcc" : "+v"(dl) : "v"(s4), "s"(o), "v"(d) : "vcc")
+        PCD_SEL(o1, d1); PCD_SEL(o2, d2); PCD_SEL(o3, d3); PCD_SEL(o4, d4);
+        PCD_SEL(o5, d5); PCD_SEL(o6, d6); PCD_SEL(o7, d7); PCD_SEL(o8, d8);
+#undef PCD_SEL
+        for (int r = 9; r < nrows; ++r) {   // other brick / halo settings have more rows
+          const uint32_t o_r = (uint32_t)__builtin_amdgcn_readlane((int)off, r);
+          const uint32_t d_r = (uint32_t)__builtin_amdgcn_readlane((int)delta, r);
+          dl = s4 >= o_r ? d_r : dl;
+        }
+        // uniform base + byte offset (64-bit: a cloud may exceed 2^28 points = 4 GiB of records)
+        const float4* gp = reinterpret_cast<const float4*>(src_bytes + ((uint64_t)(s4 + dl) << 4));
+        if (!(flags & kAblateNoDma)) {
+          // the instruction offset is added to the LDS address as well as to the source address
+          // (LDS address = M0 base + instruction offset + lane * 16): take it off the base again
+          lds_dma16_off<0>(gp, buf);
+          lds_dma16_off<16>(gp, buf + 64 - 1);
+          lds_dma16_off<32>(gp, buf + 128 - 2);
+          lds_dma16_off<48>(gp, buf + 192 - 3);
+        } else {
+          asm volatile("" ::"v"(gp));
         }
       };
-      auto run_tiles = [&](auto fast_tag) {
-        issue_tile(0, fast_tag);
-        for (int t = 0; t < ntiles; ++t) {
-          if (t + 1 < ntiles) {
-            issue_tile(t + 1, fast_tag);
-            // tile t landed, the 4 DMAs of tile t+1 still in flight
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          __builtin_amdgcn_wave_barrier();
-          // The tile is read with inline-asm ds_read_b128: for an ordinary LDS load hipcc would insert
-          // s_waitcnt vmcnt(0) (it cannot tell the two buffers apart) and drain tile t+1's DMAs.
-          f32x4 p[4];
-          const uint32_t rd = lds_addr(s_tile[wave][t & 1]) + lane * 16;
-          if (flags & kAblateNoLdsRead) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) p[k] = f32x4{(float)lane, (float)t, (float)k, 0.f};
-          } else
-          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
-                       "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
-                       "s_waitcnt lgkmcnt(0)"
-                       : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
-                       : "v"(rd)
-                       : "memory");
-          // half-filled groups (cnt <= G/2, wave-uniform) skip the empty query slots
-          if (flags & kAblateCompare) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(p[k]));
-          } else if (flags & kAblateQuarter) {   // a quarter of the compare work, everything else unchanged
-            compare_point<G>(p[0], qx, qy, qz, best);
-#pragma unroll
-            for (int k = 1; k < 4; ++k) asm volatile("" ::"v"(p[k]));
-          } else if (cnt <= G / 4) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) compare_point<G / 4>(p[k], qx, qy, qz, best);
-          } else if (cnt <= G / 2) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) compare_point<G / 2>(p[k], qx, qy, qz, best);
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) compare_point<G>(p[k], qx, qy, qz, best);
-          }
-          // (the reads of this buffer have returned -- waited inside the asm block -- before tile t+2's DMAs)
+      issue_tile(0);
+      for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) {
+          issue_tile(t + 1);
+          // tile t landed, the 4 DMAs of tile t+1 still in flight
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-      };
-      if (fast) run_tiles(std::true_type{});
-      else run_tiles(std::false_type{});
+        __builtin_amdgcn_wave_barrier();
+        // The tile is read with inline-asm ds_read_b128: for an ordinary LDS load hipcc would insert
+        // s_waitcnt vmcnt(0) (it cannot tell the two buffers apart) and drain tile t+1's DMAs.
+        f32x4 p[4];
+        const uint32_t rd = lds_addr(s_tile[wave][t & 1]) + lane * 16;
+        if (flags & kAblateNoLdsRead) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) p[k] = f32x4{(float)lane, (float)t, (float)k, 0.f};
+        } else
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                     "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
+                     : "v"(rd)
+                     : "memory");
+        // half-filled groups (cnt <= G/2, wave-uniform) skip the empty query slots
+        if (flags & kAblateCompare) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(p[k]));
+        } else if (flags & kAblateQuarter) {   // a quarter of the compare work, everything else unchanged
+          compare_point<G>(p[0], qx, qy, qz, best);
+#pragma unroll
+          for (int k = 1; k < 4; ++k) asm volatile("" ::"v"(p[k]));
+        } else if (cnt <= G / 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) compare_point<G / 4>(p[k], qx, qy, qz, best);
+        } else if (cnt <= G / 2) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) compare_point<G / 2>(p[k], qx, qy, qz, best);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) compare_point<G>(p[k], qx, qy, qz, best);
+        }
+        // (the reads of this buffer have returned -- waited inside the asm block -- before tile t+2's DMAs)
+      }
     }
     // ---- one transposed reduction for the 8 queries; lane k fetches result k ----
     uint64_t best_u[G];

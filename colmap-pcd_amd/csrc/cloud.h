@@ -9,6 +9,11 @@
 //   cell_start [ncells+1] uint32    exclusive prefix of per-cell counts
 //   blk_aabb [nodes][8] float       tight bounds {lo.xyz, hi.xyz, 0, 0}: every 4x4x4-cell block (level 0)
 //                                   followed by the coarser pyramid levels (4x4x4 children each)
+//   sub_aabb [nblocks][8][8] float  the 8 sub-blocks of 2x2x2 cells of every block: {lo.xyz, hi.xyz, bits(first
+//                                   point), bits(count)}.  A sub-block is an x-range of 2 cells of ONE quad row, i.e.
+//                                   one contiguous point range; sub = quad_row_in_block * 2 + x_half, so the two
+//                                   halves of a row are adjacent records and adjacent ranges.  The exact fallback
+//                                   prunes and addresses its leaf scans with these (no cell_start round trip)
 #pragma once
 #include "common.h"
 
@@ -45,7 +50,7 @@ struct pcd_cloud {
   uint32_t index_base = 0, index_stride = 1;
   pcd::DevBuf<float4> pts4, nrm4, sorted;
   pcd::DevBuf<uint32_t> cell_start;
-  pcd::DevBuf<float> blk_aabb;
+  pcd::DevBuf<float> blk_aabb, sub_aabb;
   pcd::GridParams grid{};
   pcd::PyramidParams pyr{};
   uint64_t ncells = 0, nblocks = 0, occupied = 0;

@@ -127,8 +127,10 @@ __global__ void k_cell_keys(const float4* __restrict__ pts4, uint64_t n, GridPar
 __global__ void k_gather_sorted(const float4* __restrict__ pts4, const uint32_t* __restrict__ order, uint64_t m,
                                 uint32_t index_base, uint32_t index_stride, float4* __restrict__ sorted) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  uint32_t src = order[i];
+  if (i >= m + 4) return;
+  // rows m .. m+3 repeat the last record: the brick kernel reads ranges in groups of 4 records and may run up to
+  // 3 records past the end of the last range (brick_kernel.h); a repeated real point cannot change a minimum
+  uint32_t src = order[i < m ? i : m - 1];
   float4 p = pts4[src];
   p.w = __uint_as_float(index_base + src * index_stride);
   sorted[i] = p;
@@ -167,6 +169,46 @@ __global__ void k_block_aabb(const float4* __restrict__ sorted, const uint32_t* 
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2];
     o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
     o[6] = 0.f; o[7] = 0.f;
+  }
+}
+
+// one wavefront per block: tight AABB + point range of each of its 8 sub-blocks (2x2x2 cells; cloud.h)
+__global__ void k_sub_aabb(const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, GridParams g,
+                           uint64_t nblocks, float* __restrict__ sub) {
+  const int lane = threadIdx.x & 63;
+  uint64_t blk = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+  if (blk >= nblocks) return;
+  int bx = (int)(blk % g.bdims[0]);
+  int by = (int)((blk / g.bdims[0]) % g.bdims[1]);
+  int bz = (int)(blk / ((uint64_t)g.bdims[0] * g.bdims[1]));
+  for (int sb = 0; sb < 8; ++sb) {
+    const int r = sb >> 1, xh = sb & 1;
+    const int yq = by * 2 + (r & 1), zq = bz * 2 + (r >> 1);
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t s = 0, e = 0;
+    if (yq < g.qdims[0] && zq < g.qdims[1]) {
+      const int cx0 = min(bx * kBlockCells + 2 * xh, g.dims[0]), cx1 = min(cx0 + 2, g.dims[0]);
+      const uint64_t rowbase = quad_row_base(g, yq, zq);
+      s = cell_start[rowbase + 4 * cx0];
+      e = cell_start[rowbase + 4 * cx1];
+      for (uint32_t i = s + lane; i < e; i += 64) {
+        const float4 p = sorted[i];
+        lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+        lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+        lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = fminf(lo[d], __shfl_xor(lo[d], off));
+        hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off));
+      }
+    if (lane == 0) {
+      float* o = sub + 8 * (blk * 8 + sb);
+      o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2];
+      o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
+      o[6] = __uint_as_float(s); o[7] = __uint_as_float(e - s);
+    }
   }
 }
 
@@ -313,7 +355,7 @@ static pcd_status build_grid(pcd_cloud* c, float user_h, hipStream_t s) {
   c->occupied = hc[0];
 
   // --- sort rows by cell (stable radix sort keeps original order inside a cell) ---
-  PCD_TRY(c->sorted.reserve(std::max<uint64_t>(c->m, 1)));
+  PCD_TRY(c->sorted.reserve(c->m + 4));   // + 4 spare records, see k_gather_sorted
   if (n) {
     DevBuf<uint32_t> k0, k1, v0, v1;
     PCD_TRY(k0.reserve(n)); PCD_TRY(k1.reserve(n)); PCD_TRY(v0.reserve(n)); PCD_TRY(v1.reserve(n));
@@ -324,7 +366,7 @@ static pcd_status build_grid(pcd_cloud* c, float user_h, hipStream_t s) {
     PCD_TRY(tmp.reserve(tb));
     PCD_HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, k0.p, k1.p, v0.p, v1.p, n, 0, 32, s));
     if (c->m)
-      hipLaunchKernelGGL(k_gather_sorted, dim3(div_up(c->m, 256)), dim3(256), 0, s, c->pts4.p, v1.p, c->m,
+      hipLaunchKernelGGL(k_gather_sorted, dim3(div_up(c->m + 4, 256)), dim3(256), 0, s, c->pts4.p, v1.p, c->m,
                          c->index_base, c->index_stride, c->sorted.p);
     PCD_HIP_TRY(hipStreamSynchronize(s));
   }
@@ -347,6 +389,9 @@ static pcd_status build_grid(pcd_cloud* c, float user_h, hipStream_t s) {
   PCD_TRY(c->blk_aabb.reserve(8 * total_nodes));
   hipLaunchKernelGGL(k_block_aabb, dim3(div_up(c->nblocks * 64, 256)), dim3(256), 0, s, c->sorted.p,
                      c->cell_start.p, g, c->nblocks, c->blk_aabb.p);
+  PCD_TRY(c->sub_aabb.reserve(64 * std::max<uint64_t>(c->nblocks, 1)));
+  hipLaunchKernelGGL(k_sub_aabb, dim3(div_up(c->nblocks * 64, 256)), dim3(256), 0, s, c->sorted.p,
+                     c->cell_start.p, g, c->nblocks, c->sub_aabb.p);
   for (int l = 1; l < py.nlev; ++l) {
     const int* cd = py.dims[l - 1];
     const int* pd = py.dims[l];

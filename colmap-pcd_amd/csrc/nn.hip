@@ -408,6 +408,7 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, ui
 __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams py, const float4* __restrict__ sorted,
                                                       const uint32_t* __restrict__ cell_start,
                                                       const float* __restrict__ aabb,
+                                                      const float* __restrict__ sub_aabb,
                                                       const float4* __restrict__ qf4,
                                                       const uint32_t* __restrict__ list,  // NULL: queries 0..count-1
                                                       const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
@@ -468,29 +469,33 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
       ny = 4 * s_node[wave][lev][1] + ((sl >> 2) & 3);
       nz = 4 * s_node[wave][lev][2] + (sl >> 4);
       if (lev == 1) {
-        // (nx,ny,nz) is a block: 2x2 quad rows of 4 x-cells, each one contiguous point range (grid.h)
-        uint32_t rs = 0, re = 0;
-        if (lane < 4) {
-          const int yq = ny * 2 + (lane & 1), zq = nz * 2 + (lane >> 1);
-          if (yq < g.qdims[0] && zq < g.qdims[1]) {
-            const int cx0 = nx * kBlockCells, cx1 = min(cx0 + kBlockCells, g.dims[0]);
-            const uint64_t rowbase = quad_row_base(g, yq, zq);
-            rs = cell_start[rowbase + 4 * cx0];
-            re = cell_start[rowbase + 4 * cx1];
+        // (nx,ny,nz) is a block.  Its 8 sub-blocks of 2x2x2 cells are contiguous point ranges with their own tight
+        // boxes (cloud.h sub_aabb: {lo, hi, first point, count}, one 32-B record each): lanes 0..7 test them with
+        // the same exact bound as the pyramid nodes and only the survivors are scanned -- no cell_start round trip,
+        // and roughly half the points of a block that a plane crosses never leave HBM.
+        uint32_t rs = 0, rn = 0;
+        if (lane < 8) {
+          const uint64_t blk = ((uint64_t)nz * g.bdims[1] + ny) * g.bdims[0] + nx;
+          const float4 lo = *reinterpret_cast<const float4*>(sub_aabb + 8 * (blk * 8 + lane));      // lo.xyz hi.x
+          const float4 hi = *reinterpret_cast<const float4*>(sub_aabb + 8 * (blk * 8 + lane) + 4);  // hi.y hi.z start count
+          const uint32_t cnt = __float_as_uint(hi.w);
+          if (cnt) {
+            const float px = fminf(fmaxf(qx, lo.x), lo.w), pyc = fminf(fmaxf(qy, lo.y), hi.x),
+                        pz = fminf(fmaxf(qz, lo.z), hi.y);
+            if (l2_simple3(qx, qy, qz, px, pyc, pz) <= best_d) { rs = __float_as_uint(hi.z); rn = cnt; }
           }
         }
-        // The 4 ranges are scanned as one concatenated range, 256 points per step, with the four loads of
+        // The surviving ranges are scanned as one concatenated range, 256 points per step, with the four loads of
         // a step issued back to back (clamped indices, no branches around them).  Range starts and source
-        // deltas are wave-uniform (SGPRs): slot -> address is three compares, no LDS.
+        // deltas are wave-uniform (SGPRs): slot -> address is seven compares, no LDS.
         uint32_t Tb;
-        const uint32_t roff = wave_excl_scan_u32(re - rs, Tb);
-        const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)roff, 1);
-        const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)roff, 2);
-        const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)roff, 3);
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)rs, 0);
-        const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)rs, 1) - o1;
-        const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)rs, 2) - o2;
-        const uint32_t d3 = (uint32_t)__builtin_amdgcn_readlane((int)rs, 3) - o3;
+        const uint32_t roff = wave_excl_scan_u32(rn, Tb);
+        uint32_t o[8], dd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          o[k] = (uint32_t)__builtin_amdgcn_readlane((int)roff, k);
+          dd[k] = (uint32_t)__builtin_amdgcn_readlane((int)rs, k) - o[k];
+        }
         for (uint32_t base = 0; base < Tb; base += 256) {
           float4 p[4];
 #pragma unroll
@@ -498,7 +503,9 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
             uint32_t gi = base + k * 64 + lane;
             gi = gi < Tb ? gi : Tb - 1;
             // empty ranges share their offset with the next one: test from the last range down
-            const uint32_t dl = gi >= o3 ? d3 : gi >= o2 ? d2 : gi >= o1 ? d1 : d0;
+            uint32_t dl = dd[0];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) dl = gi >= o[r] ? dd[r] : dl;
             p[k] = sorted[gi + dl];
           }
 #pragma unroll
@@ -583,7 +590,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
                        &sc->counters.p->fb_count, sc->fb_dense.p, &sc->counters.p->pad[0]);
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), 256 * 8);
     hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, g, c->pyr, c->sorted.p, c->cell_start.p,
-                       c->blk_aabb.p, sc->qf4.p, sc->fb_dense.p, &sc->counters.p->pad[0], 0u, d_keys,
+                       c->blk_aabb.p, c->sub_aabb.p, sc->qf4.p, sc->fb_dense.p, &sc->counters.p->pad[0], 0u, d_keys,
                        sc->counters.p, g_collect_stats);
   }
   return PCD_OK;
@@ -630,7 +637,7 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
       ScopedKernelTimer t("nn_fallback", s);
       const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), 256 * 8);
       hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, c->grid, c->pyr, c->sorted.p, c->cell_start.p,
-                         c->blk_aabb.p, sc->qf4.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)Q,
+                         c->blk_aabb.p, c->sub_aabb.p, sc->qf4.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)Q,
                          d_keys, sc->counters.p, g_collect_stats);
     } else if (algo == PCD_NN_AUTO || algo == PCD_NN_GRID) {
       PCD_TRY(run_grid<8>(c, sc, Q, d_keys, s, refine || bound != nullptr));   // incoming keys matter: carry them
