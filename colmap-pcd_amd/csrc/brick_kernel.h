@@ -68,35 +68,56 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
 }
 __device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b) { return b < a ? b : a; }
 
-// All-lanes minimum of 8 per-lane values at once.  Returns, in every lane, the minimum of value
-// index ((lane>>5)&1)*4 + ((lane>>4)&1)*2 + ((lane>>3)&1).
-__device__ __forceinline__ uint64_t wave_min8_u64(const uint64_t (&v)[8]) {
+// All-lanes minimum of 8 per-lane packed keys at once (the keys as f64, see compare_point: v_min_f64 on them
+// is the lexicographic (distance, index) minimum; none of them is a NaN pattern here).  Returns, in every lane,
+// the minimum of value index ((lane>>5)&1)*4 + ((lane>>4)&1)*2 + ((lane>>3)&1).
+// A reduce-scatter: each stage halves the number of values a lane still carries.  The first two stages are the
+// gfx950 lane-swap instructions: v_permlane32_swap exchanges lanes 32..63 of one register with lanes 0..31 of
+// another, so after swapping the registers of values i and 4+i the lane-wise minimum of the pair IS "value i over
+// both halves" in lanes 0..31 and "value 4+i over both halves" in lanes 32..63 -- 2 swaps + 1 v_min_f64 per pair
+// where select + ds_bpermute + 64-bit compare/select took 13 instructions; v_permlane16_swap does the same for
+// the 16-lane rows.  The remaining 8-lane groups are folded with DPP moves (row_ror:8 with a select, then
+// row_half_mirror, quad_perm xor 2, quad_perm xor 1).
+__device__ __forceinline__ double min_key_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = __builtin_amdgcn_update_dpp(0u, (uint32_t)u, CTRL, 0xf, 0xf, false);
+  const uint32_t hi = __builtin_amdgcn_update_dpp(0u, (uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+template <int ROW>  // 32 or 16: min over the swapped pair (x keeps the even rows' value, y the odd rows')
+__device__ __forceinline__ double swap_min_f64(double x, double y) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const uint64_t ux = __builtin_bit_cast(uint64_t, x), uy = __builtin_bit_cast(uint64_t, y);
+  u32x2 lo, hi;
+  if (ROW == 32) {
+    lo = __builtin_amdgcn_permlane32_swap((uint32_t)ux, (uint32_t)uy, false, false);
+    hi = __builtin_amdgcn_permlane32_swap((uint32_t)(ux >> 32), (uint32_t)(uy >> 32), false, false);
+  } else {
+    lo = __builtin_amdgcn_permlane16_swap((uint32_t)ux, (uint32_t)uy, false, false);
+    hi = __builtin_amdgcn_permlane16_swap((uint32_t)(ux >> 32), (uint32_t)(uy >> 32), false, false);
+  }
+  return min_key_f64(__builtin_bit_cast(double, ((uint64_t)hi.x << 32) | lo.x),
+                     __builtin_bit_cast(double, ((uint64_t)hi.y << 32) | lo.y));
+}
+__device__ __forceinline__ double wave_min8_key(const double (&v)[8]) {
   const int lane = threadIdx.x & 63;
-  uint64_t a[4], b2[2], c;
-  {
-    const bool up = lane & 32;  // upper half keeps 4..7, sends 0..3
+  double a[4], b2[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint64_t keep = up ? v[4 + i] : v[i], send = up ? v[i] : v[4 + i];
-      a[i] = min_u64(keep, shfl_xor_u64(send, 32));
-    }
-  }
-  {
-    const bool up = lane & 16;
+  for (int i = 0; i < 4; ++i) a[i] = swap_min_f64<32>(v[i], v[4 + i]);   // lanes 0..31: value i, 32..63: value 4+i
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const uint64_t keep = up ? a[2 + i] : a[i], send = up ? a[i] : a[2 + i];
-      b2[i] = min_u64(keep, shfl_xor_u64(send, 16));
-    }
-  }
-  {
-    const bool up = lane & 8;
-    const uint64_t keep = up ? b2[1] : b2[0], send = up ? b2[0] : b2[1];
-    c = min_u64(keep, shfl_xor_u64(send, 8));
-  }
-  c = min_u64(c, shfl_xor_u64(c, 4));
-  c = min_u64(c, shfl_xor_u64(c, 2));
-  c = min_u64(c, shfl_xor_u64(c, 1));
+  for (int i = 0; i < 2; ++i) b2[i] = swap_min_f64<16>(a[i], a[2 + i]);  // even rows: a[i], odd rows: a[2+i]
+  const bool up = lane & 8;
+  const double keep = up ? b2[1] : b2[0], send = up ? b2[0] : b2[1];
+  double c = min_key_f64(keep, dpp_f64<0x128>(send));   // row_ror:8 = lane ^ 8 inside a row of 16
+  c = min_key_f64(c, dpp_f64<0x141>(c));                // row_half_mirror: lane <- 7 - lane inside each 8
+  c = min_key_f64(c, dpp_f64<0x4E>(c));                 // quad_perm [2,3,0,1]
+  c = min_key_f64(c, dpp_f64<0xB1>(c));                 // quad_perm [1,0,3,2]
   return c;
 }
 
@@ -381,10 +402,7 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
       }
     }
     // ---- one transposed reduction for the 8 queries; lane k fetches result k ----
-    uint64_t best_u[G];
-#pragma unroll
-    for (int k = 0; k < G; ++k) best_u[k] = __builtin_bit_cast(uint64_t, best[k]);
-    const uint64_t red = (flags & kAblateReduce) ? best_u[0] : wave_min8_u64(best_u);
+    const uint64_t red = __builtin_bit_cast(uint64_t, (flags & kAblateReduce) ? best[0] : wave_min8_key(best));
     // value index v sits in lanes with bits (5,4,3) = v  ->  lane 8*bitrev... v = b5*4 + b4*2 + b3
     const int holder = ((lane & 4) ? 32 : 0) | ((lane & 2) ? 16 : 0) | ((lane & 1) ? 8 : 0);
     uint64_t mine = ((uint64_t)__shfl((uint32_t)(red >> 32), holder) << 32) | __shfl((uint32_t)red, holder);
