@@ -193,8 +193,8 @@ __device__ __forceinline__ int item_count(const uint4 it) { return (int)(it.w >>
 __device__ __forceinline__ void brick_region(const GridParams& g, const BrickParams& b, const uint4 it, int c0[3],
                                              int c1[3]) {
   const int bx = (int)it.y, by = (int)it.z, bz = (int)(it.w & 0x0FFFFFFFu);
-  c0[0] = max(bx * b.B - b.R, 0); c0[1] = max(by * b.B - b.R, 0); c0[2] = max(bz * b.B - b.R, 0);
-  c1[0] = min(bx * b.B + b.B + b.R, g.dims[0]); c1[1] = min(by * b.B + b.B + b.R, g.dims[1]);
+  c0[0] = max(bx * b.Bx - b.R, 0); c0[1] = max(by * b.B - b.R, 0); c0[2] = max(bz * b.B - b.R, 0);
+  c1[0] = min(bx * b.Bx + b.Bx + b.R, g.dims[0]); c1[1] = min(by * b.B + b.B + b.R, g.dims[1]);
   c1[2] = min(bz * b.B + b.B + b.R, g.dims[2]);
 }
 

@@ -60,16 +60,17 @@ constexpr uint64_t kSmallBatch = 65536;
 
 // ------------------------------------------------------------ brick math ---
 struct BrickParams {
-  int B, R;        // brick edge in cells, halo in cells
+  int B, R;        // brick edge in cells (y, z), halo in cells
+  int Bx;          // brick length along x in cells (the rows of the region run along x)
   int nb[3];       // bricks per axis
   uint32_t nbricks;
 };
 
-static BrickParams make_bricks(const GridParams& g, int B, int R) {
+static BrickParams make_bricks(const GridParams& g, int B, int Bx, int R) {
   BrickParams b;
-  b.B = B; b.R = R;
+  b.B = B; b.R = R; b.Bx = Bx;
   uint64_t n = 1;
-  for (int d = 0; d < 3; ++d) { b.nb[d] = (g.dims[d] + B - 1) / B; n *= (uint64_t)b.nb[d]; }
+  for (int d = 0; d < 3; ++d) { const int e = d == 0 ? Bx : B; b.nb[d] = (g.dims[d] + e - 1) / e; n *= (uint64_t)b.nb[d]; }
   b.nbricks = (uint32_t)n;
   return b;
 }
@@ -201,7 +202,7 @@ __global__ void k_brick_keys(const float4* __restrict__ qf4, uint64_t Q, GridPar
     const int cy = cell_coord_raw(q.y, g.origin[1], g.inv_h, g.dims[1]);
     const int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
     const bool in = cx >= 0 && cx < g.dims[0] && cy >= 0 && cy < g.dims[1] && cz >= 0 && cz < g.dims[2];
-    bid = in ? (uint32_t)(((uint64_t)(cz / b.B) * b.nb[1] + (cy / b.B)) * b.nb[0] + (cx / b.B)) : b.nbricks;
+    bid = in ? (uint32_t)(((uint64_t)(cz / b.B) * b.nb[1] + (cy / b.B)) * b.nb[0] + (cx / b.Bx)) : b.nbricks;
   }
   keys[i] = bid;
   vals[i] = (uint32_t)i;
@@ -543,7 +544,9 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   const GridParams& g = c->grid;
   int B = g_brick_B, R = g_brick_R;
   if ((B + 2 * R) * (B + 2 * R) > kMaxRows) { B = 2; R = 2; }
-  const BrickParams b = make_bricks(g, B, R);
+  // x-long bricks (Bx = 2B, 3B, 4B: fewer, fuller groups but a longer region per query) were measured on workload M:
+  // 0.638 / 0.698 / 0.768 ms against 0.633 ms for cubes (profiles/r02_nn_config_sweeps.txt)
+  const BrickParams b = make_bricks(g, B, B, R);
   PCD_TRY(sc->qsorted.reserve(Q));
   PCD_TRY(sc->ksorted.reserve(Q));
   // fallback list: one slot per query + the chunk slack of every wavefront of the brick kernel (brick_kernel.h)
