@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -197,16 +198,14 @@ __global__ __launch_bounds__(256) void k_sift_scores(const uint8_t* __restrict__
 // multiplied and scanned (one __syncthreads per tile).  The best-of-set-2 results of the stripe's rows stay
 // in registers across the walk (one partial per chunk); the best-of-set-1 results of a column tile are
 // written per 64-row half (no cross-wave merge inside the loop).  part12 [nchunk][n1], part21 [2 nby][n2].
-__global__ __launch_bounds__(256, 2) void k_sift_scores_stripe(const uint8_t* __restrict__ d1, int n1,
-                                                            const uint8_t* __restrict__ d2, int n2,
-                                                            const int* __restrict__ sum1, const int* __restrict__ sum2,
-                                                            int4* __restrict__ part12, int4* __restrict__ part21,
-                                                            int nbx, int ct_per_chunk) {
+__device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int n1, const uint8_t* __restrict__ d2,
+                                            int n2, const int* __restrict__ sum1, const int* __restrict__ sum2,
+                                            int4* __restrict__ part12, int4* __restrict__ part21, int nbx,
+                                            int ct_per_chunk, const int chunk, const int by) {
   __shared__ __attribute__((aligned(16))) uint8_t sA[kSiftTile * kSiftPitch];
   __shared__ __attribute__((aligned(16))) uint8_t sB[2][kSiftTile * kSiftPitch];
   __shared__ int sSumA[kSiftTile], sSumB[2][kSiftTile];
   __shared__ int4 sMerge[2][64];   // [64-column half of the stripe][column]
-  const int chunk = blockIdx.x, by = blockIdx.y;
   const int row0 = by * kSiftTile;
   const int bx0 = chunk * ct_per_chunk, bx1 = min(bx0 + ct_per_chunk, nbx);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -346,12 +345,42 @@ __global__ __launch_bounds__(256, 2) void k_sift_scores_stripe(const uint8_t* __
   }
 }
 
+__global__ __launch_bounds__(256, 2) void k_sift_scores_stripe(const uint8_t* __restrict__ d1, int n1,
+                                                            const uint8_t* __restrict__ d2, int n2,
+                                                            const int* __restrict__ sum1, const int* __restrict__ sum2,
+                                                            int4* __restrict__ part12, int4* __restrict__ part21,
+                                                            int nbx, int ct_per_chunk) {
+  sift_stripe(d1, n1, d2, n2, sum1, sum2, part12, part21, nbx, ct_per_chunk, blockIdx.x, blockIdx.y);
+}
+
+// ---- many image pairs in one launch set (pcd_sift_match_batch_device) ----------------------------------
+// All descriptors live in one arena; a pair names two row ranges of it.  blockIdx.z = pair; the grid's x / y
+// extents are sized for the largest pair of the batch, smaller pairs leave early.
+struct SiftPairDev {
+  uint32_t row1, n1, row2, n2;   // arena rows of the two images
+  uint64_t part12, part21;       // int4 offsets of the pair's partial results
+  uint64_t m12, m21;             // int offsets of the pair's best-match arrays
+  uint64_t match;                // offset (in matches) of the pair's output list
+};
+
+__global__ __launch_bounds__(256, 2) void k_sift_scores_batch(const uint8_t* __restrict__ arena,
+                                                           const int* __restrict__ sum,
+                                                           const SiftPairDev* __restrict__ pairs,
+                                                           int4* __restrict__ part12, int4* __restrict__ part21,
+                                                           int nchunk) {
+  const SiftPairDev pr = pairs[blockIdx.z];
+  const int nbx = ((int)pr.n2 + kSiftTile - 1) / kSiftTile, nby = ((int)pr.n1 + kSiftTile - 1) / kSiftTile;
+  if ((int)blockIdx.y >= nby) return;
+  const int ct = (nbx + nchunk - 1) / nchunk;   // chunks past the pair's last column tile leave inside sift_stripe
+  sift_stripe(arena + (size_t)pr.row1 * 128, (int)pr.n1, arena + (size_t)pr.row2 * 128, (int)pr.n2, sum + pr.row1,
+              sum + pr.row2, part12 + pr.part12, part21 + pr.part21, nbx, ct, blockIdx.x, blockIdx.y);
+}
+
 // sift.cc:72-104: merge the per-tile triples in ascending tile order, then the distance / ratio tests.
 // One launch for both directions: threads [0, n1) finish set 1 -> 2, threads [n1, n1 + n2) set 2 -> 1.
-__global__ __launch_bounds__(256) void k_sift_finalize(const int4* __restrict__ part12, int n1, int nbx,
-                                                       const int4* __restrict__ part21, int n2, int nby,
-                                                       float max_ratio, float max_distance, int* __restrict__ m12,
-                                                       int* __restrict__ m21) {
+__device__ __forceinline__ void sift_finalize(const int4* __restrict__ part12, int n1, int nbx,
+                                              const int4* __restrict__ part21, int n2, int nby, float max_ratio,
+                                              float max_distance, int* __restrict__ m12, int* __restrict__ m21) {
   // 16 lanes per descriptor: lane p merges tiles p, p + 16, ... in ascending order, then a 4-step butterfly.
   // On equal best scores the lower index wins, which is the earlier tile (indices ascend with the tile) --
   // the same winner as the reference's single ascending scan.
@@ -384,12 +413,31 @@ __global__ __launch_bounds__(256) void k_sift_finalize(const int4* __restrict__ 
   (first ? m12 : m21)[i] = m;
 }
 
+__global__ __launch_bounds__(256) void k_sift_finalize(const int4* __restrict__ part12, int n1, int nbx,
+                                                       const int4* __restrict__ part21, int n2, int nby,
+                                                       float max_ratio, float max_distance, int* __restrict__ m12,
+                                                       int* __restrict__ m21) {
+  sift_finalize(part12, n1, nbx, part21, n2, nby, max_ratio, max_distance, m12, m21);
+}
+
+__global__ __launch_bounds__(256) void k_sift_finalize_batch(const SiftPairDev* __restrict__ pairs,
+                                                             const int4* __restrict__ part12,
+                                                             const int4* __restrict__ part21, int nchunk,
+                                                             float max_ratio, float max_distance, int* __restrict__ m12,
+                                                             int* __restrict__ m21) {
+  const SiftPairDev pr = pairs[blockIdx.z];
+  const int nbx = ((int)pr.n2 + kSiftTile - 1) / kSiftTile, nby = ((int)pr.n1 + kSiftTile - 1) / kSiftTile;
+  const int ct = max(1, (nbx + nchunk - 1) / nchunk), used = (nbx + ct - 1) / ct;   // chunks that wrote a partial
+  sift_finalize(part12 + pr.part12, (int)pr.n1, used, part21 + pr.part21, (int)pr.n2, 2 * nby, max_ratio, max_distance,
+                m12 + pr.m12, m21 + pr.m21);
+}
+
 // sift.cc:118-143 for n1 <= 1024 * kCompactPer: cross check, ordered compaction and count in ONE workgroup
 // (a launch costs more than the work: 8192 flags).  Larger sets take the three-kernel path below.
 constexpr int kCompactPer = 16;
-__global__ __launch_bounds__(1024) void k_sift_keep_compact(const int* __restrict__ m12, const int* __restrict__ m21,
-                                                            int n1, int cross_check, uint32_t* __restrict__ matches,
-                                                            int* __restrict__ count) {
+__device__ __forceinline__ void sift_keep_compact(const int* __restrict__ m12, const int* __restrict__ m21, int n1,
+                                                  int cross_check, uint32_t* __restrict__ matches,
+                                                  int* __restrict__ count) {
   __shared__ uint32_t s_wave[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (n1 + 1023) / 1024;            // <= kCompactPer consecutive rows per thread
@@ -430,6 +478,35 @@ __global__ __launch_bounds__(1024) void k_sift_keep_compact(const int* __restric
   if (tid == 0) *count = (int)total;
 }
 
+__global__ __launch_bounds__(1024) void k_sift_keep_compact(const int* __restrict__ m12, const int* __restrict__ m21,
+                                                            int n1, int cross_check, uint32_t* __restrict__ matches,
+                                                            int* __restrict__ count) {
+  sift_keep_compact(m12, m21, n1, cross_check, matches, count);
+}
+
+// one workgroup per pair
+__global__ __launch_bounds__(1024) void k_sift_keep_compact_batch(const SiftPairDev* __restrict__ pairs,
+                                                                  const int* __restrict__ m12,
+                                                                  const int* __restrict__ m21, int cross_check,
+                                                                  uint32_t* __restrict__ matches,
+                                                                  int* __restrict__ counts) {
+  const SiftPairDev pr = pairs[blockIdx.x];
+  sift_keep_compact(m12 + pr.m12, m21 + pr.m21, (int)pr.n1, cross_check, matches + 2 * pr.match, counts + blockIdx.x);
+}
+
+// dense packing of the per-pair lists (host entry): list p moves from matches_in + 2 * src_off[p] to
+// matches_out + 2 * dense_off[p]
+__global__ __launch_bounds__(256) void k_sift_pack_lists(const uint64_t* __restrict__ src_off,
+                                                         const int* __restrict__ counts,
+                                                         const uint64_t* __restrict__ dense_off,
+                                                         const uint32_t* __restrict__ matches_in,
+                                                         uint32_t* __restrict__ matches_out) {
+  const int p = blockIdx.x;
+  const uint2* __restrict__ src = reinterpret_cast<const uint2*>(matches_in) + src_off[p];
+  uint2* __restrict__ dst = reinterpret_cast<uint2*>(matches_out) + dense_off[p];
+  for (int i = threadIdx.x; i < counts[p]; i += blockDim.x) dst[i] = src[i];
+}
+
 // sift.cc:118-143: keep flags, in set-1 order
 __global__ void k_sift_keep(const int* __restrict__ m12, const int* __restrict__ m21, int n1, int cross_check,
                             uint32_t* __restrict__ keep) {
@@ -455,6 +532,12 @@ struct SiftScratch {
   DevBuf<int4> part12, part21;
   DevBuf<uint32_t> keep, pos, matches;
   DevBuf<char> tmp;
+  // batch entry
+  DevBuf<uint8_t> arena;
+  DevBuf<SiftPairDev> pairs;
+  DevBuf<int> counts;
+  DevBuf<uint64_t> dense_off;
+  DevBuf<uint32_t> dense;
 };
 static SiftScratch* g_sift[64] = {nullptr};
 static int g_sift_tile_kernel = 0;   // 1 = one 128x128 tile per workgroup (the first design; A/B timing via PCD_SIFT_TILE=1)
@@ -512,6 +595,115 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
   return PCD_OK;
 }
 
+
+// Many pairs over one descriptor arena.  Sub-batches are cut so that the partial results of a sub-batch stay under
+// kSiftBatchPartials int4 (2 GiB); each sub-batch is three launches (scores, finalize, cross check + compaction),
+// the arena's row sums one launch in front.  Nothing synchronises with the host.
+constexpr size_t kSiftBatchPartials = (size_t)1 << 27;   // PCD_SIFT_BATCH_PARTIALS overrides it (tests: forces the cuts)
+
+static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const uint64_t* first_row, int n_images,
+                                    const uint32_t* pair_ids, int n_pairs, float max_ratio, float max_distance,
+                                    int cross_check, uint32_t* d_matches, const uint64_t* match_offset, int* d_counts,
+                                    SiftScratch& sc, hipStream_t s) {
+  const uint64_t total_rows = first_row[n_images];
+  PCD_REQUIRE(total_rows < (1ull << 32), "arena larger than 2^32 descriptors");
+  const char* budget_env = std::getenv("PCD_SIFT_BATCH_PARTIALS");
+  const size_t budget = budget_env ? (size_t)std::strtoull(budget_env, nullptr, 10) : kSiftBatchPartials;
+  for (int i = 0; i < n_images; ++i) PCD_REQUIRE(first_row[i] <= first_row[i + 1], "first_row must ascend");
+  bool wide = false;   // a set too long for the one-workgroup compaction: those batches run pair by pair
+  for (int p = 0; p < n_pairs; ++p) {
+    PCD_REQUIRE(pair_ids[2 * p] < (uint32_t)n_images && pair_ids[2 * p + 1] < (uint32_t)n_images, "pair names an image outside the arena");
+    const uint64_t n1 = first_row[pair_ids[2 * p] + 1] - first_row[pair_ids[2 * p]];
+    const uint64_t n2 = first_row[pair_ids[2 * p + 1] + 1] - first_row[pair_ids[2 * p + 1]];
+    PCD_REQUIRE(n1 < (1u << 30) && n2 < (1u << 30), "image too large");
+    wide = wide || n1 > (uint64_t)1024 * kCompactPer;
+  }
+  if (wide) {
+    for (int p = 0; p < n_pairs; ++p) {
+      const uint32_t a = pair_ids[2 * p], b = pair_ids[2 * p + 1];
+      const int n1 = (int)(first_row[a + 1] - first_row[a]), n2 = (int)(first_row[b + 1] - first_row[b]);
+      if (n1 == 0 || n2 == 0) { PCD_HIP_TRY(hipMemsetAsync(d_counts + p, 0, sizeof(int), s)); continue; }
+      PCD_TRY(sc.m12.reserve(n1)); PCD_TRY(sc.m21.reserve(n2));
+      PCD_TRY(sift_device(device, d_arena + first_row[a] * 128, n1, d_arena + first_row[b] * 128, n2, max_ratio,
+                          max_distance, cross_check, sc.m12.p, sc.m21.p, d_matches + 2 * match_offset[p], d_counts + p,
+                          sc, s));
+    }
+    return PCD_OK;
+  }
+  PCD_TRY(sc.sum1.reserve(total_rows));
+  if (total_rows) {
+    ScopedKernelTimer t("sift_rowsum", s);
+    hipLaunchKernelGGL(k_sift_rowsum, dim3(div_up(total_rows, 256)), dim3(256), 0, s, d_arena, (int)total_rows, sc.sum1.p,
+                       (const uint8_t*)nullptr, 0, (int*)nullptr);
+  }
+  // pair table for the whole call (uploaded once; sub-batches index into it)
+  std::vector<SiftPairDev> tab((size_t)n_pairs);
+  std::vector<int> cut;   // sub-batch boundaries
+  std::vector<int> cut_nchunk;
+  cut.push_back(0);
+  size_t max12 = 0, max21 = 0, maxm12 = 0, maxm21 = 0;
+  {
+    int p0 = 0;
+    while (p0 < n_pairs) {
+      // how many column chunks per row stripe: enough workgroups to fill the chip twice when the batch is small
+      // (decided on the first pair's size and the pairs left; any value gives the same results)
+      const uint32_t a0 = pair_ids[2 * p0], b0 = pair_ids[2 * p0 + 1];
+      const int nby0 = std::max<int>(1, (int)((first_row[a0 + 1] - first_row[a0] + kSiftTile - 1) / kSiftTile));
+      const int nbx0 = std::max<int>(1, (int)((first_row[b0 + 1] - first_row[b0] + kSiftTile - 1) / kSiftTile));
+      const long left = n_pairs - p0;
+      const int nchunk = (int)std::max<long>(1, std::min<long>(nbx0, (512 + nby0 * left - 1) / (nby0 * left)));
+      size_t o12 = 0, o21 = 0, om12 = 0, om21 = 0;
+      int p = p0;
+      for (; p < n_pairs; ++p) {
+        const uint32_t a = pair_ids[2 * p], b = pair_ids[2 * p + 1];
+        uint64_t n1 = first_row[a + 1] - first_row[a], n2 = first_row[b + 1] - first_row[b];
+        if (n1 == 0 || n2 == 0) n1 = n2 = 0;   // an empty image: no matches (sift_test.cc:311-318); every kernel skips the pair
+        const size_t nby = (n1 + kSiftTile - 1) / kSiftTile;
+        const size_t need12 = (size_t)nchunk * n1, need21 = 2 * nby * n2;
+        if (p > p0 && (o12 + need12 + o21 + need21 > budget || p - p0 >= 65535)) break;
+        tab[p] = SiftPairDev{(uint32_t)first_row[a], (uint32_t)n1, (uint32_t)first_row[b], (uint32_t)n2, o12, o21, om12, om21,
+                             match_offset[p]};
+        o12 += need12; o21 += need21; om12 += n1; om21 += n2;
+      }
+      max12 = std::max(max12, o12); max21 = std::max(max21, o21);
+      maxm12 = std::max(maxm12, om12); maxm21 = std::max(maxm21, om21);
+      cut.push_back(p);
+      cut_nchunk.push_back(nchunk);
+      p0 = p;
+    }
+  }
+  PCD_TRY(sc.pairs.reserve(n_pairs));
+  PCD_TRY(sc.part12.reserve(max12)); PCD_TRY(sc.part21.reserve(max21));
+  PCD_TRY(sc.m12.reserve(maxm12)); PCD_TRY(sc.m21.reserve(maxm21));
+  // blocking copy from pageable memory: complete when it returns, so `tab` may go out of scope
+  PCD_HIP_TRY(hipMemcpy(sc.pairs.p, tab.data(), sizeof(SiftPairDev) * (size_t)n_pairs, hipMemcpyHostToDevice));
+  for (size_t k = 0; k + 1 < cut.size(); ++k) {
+    const int p0 = cut[k], np = cut[k + 1] - cut[k], nchunk = cut_nchunk[k];
+    uint32_t mx1 = 0, mx2 = 0, mxsum = 0;
+    for (int p = p0; p < p0 + np; ++p) {
+      mx1 = std::max(mx1, tab[p].n1); mx2 = std::max(mx2, tab[p].n2); mxsum = std::max(mxsum, tab[p].n1 + tab[p].n2);
+    }
+    if (mx1 && mx2) {
+      {
+        ScopedKernelTimer t("sift_scores", s);
+        hipLaunchKernelGGL(k_sift_scores_batch, dim3(nchunk, (mx1 + kSiftTile - 1) / kSiftTile, np), dim3(256), 0, s, d_arena,
+                           sc.sum1.p, sc.pairs.p + p0, sc.part12.p, sc.part21.p, nchunk);
+      }
+      {
+        ScopedKernelTimer t("sift_finalize", s);
+        hipLaunchKernelGGL(k_sift_finalize_batch, dim3(div_up((uint64_t)mxsum * 16, 256), 1, np), dim3(256), 0, s,
+                           sc.pairs.p + p0, sc.part12.p, sc.part21.p, nchunk, max_ratio, max_distance, sc.m12.p, sc.m21.p);
+      }
+    }
+    {
+      ScopedKernelTimer t("sift_compact", s);
+      hipLaunchKernelGGL(k_sift_keep_compact_batch, dim3(np), dim3(1024), 0, s, sc.pairs.p + p0, sc.m12.p, sc.m21.p,
+                         cross_check, d_matches, d_counts + p0);
+    }
+  }
+  PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
 }  // namespace pcd
 
 using namespace pcd;
@@ -568,6 +760,73 @@ pcd_status pcd_sift_match(int device, const uint8_t* desc1, int n1, const uint8_
   return PCD_OK;
 }
 
+
+pcd_status pcd_sift_match_batch_device(int device, const uint8_t* d_arena, const uint64_t* first_row, int n_images,
+                                       const uint32_t* pairs, int n_pairs, float max_ratio, float max_distance,
+                                       int cross_check, uint32_t* d_matches, const uint64_t* match_offset,
+                                       int32_t* d_counts, void* stream) {
+  PCD_REQUIRE(n_images >= 0 && n_pairs >= 0 && first_row, "sizes / first_row");
+  if (n_pairs == 0) return PCD_OK;
+  PCD_REQUIRE(pairs && match_offset && d_counts && d_matches, "null pointer");
+  PCD_REQUIRE(first_row[n_images] == 0 || d_arena, "null arena");
+  PCD_REQUIRE(device >= 0 && device < 64, "device ordinal");
+  PCD_TRY(require_device(device));
+  std::lock_guard<std::mutex> g(g_sift_mu);
+  if (!g_sift[device]) g_sift[device] = new SiftScratch();
+  return sift_batch_device(device, d_arena, first_row, n_images, pairs, n_pairs, max_ratio, max_distance, cross_check,
+                           d_matches, match_offset, d_counts, *g_sift[device], (hipStream_t)stream);
+}
+
+pcd_status pcd_sift_match_batch(int device, const uint8_t* arena, const uint64_t* first_row, int n_images,
+                                const uint32_t* pairs, int n_pairs, float max_ratio, float max_distance, int cross_check,
+                                uint32_t* matches, uint64_t matches_capacity, uint64_t* list_offset) {
+  PCD_REQUIRE(n_images >= 0 && n_pairs >= 0 && first_row && list_offset, "sizes / first_row / list_offset");
+  list_offset[0] = 0;
+  if (n_pairs == 0) return PCD_OK;
+  PCD_REQUIRE(pairs, "null pair list");
+  PCD_REQUIRE(device >= 0 && device < 64, "device ordinal");
+  PCD_TRY(require_device(device));
+  const uint64_t rows = first_row[n_images];
+  PCD_REQUIRE(rows == 0 || arena, "null arena");
+  SiftScratch* sc;
+  {
+    std::lock_guard<std::mutex> g(g_sift_mu);
+    if (!g_sift[device]) g_sift[device] = new SiftScratch();
+    sc = g_sift[device];
+  }
+  // worst-case list of pair p: one match per descriptor of its first image
+  std::vector<uint64_t> off((size_t)n_pairs + 1, 0);
+  for (int p = 0; p < n_pairs; ++p) {
+    PCD_REQUIRE(pairs[2 * p] < (uint32_t)n_images && pairs[2 * p + 1] < (uint32_t)n_images, "pair names an image outside the arena");
+    off[p + 1] = off[p] + (first_row[pairs[2 * p] + 1] - first_row[pairs[2 * p]]);
+  }
+  PCD_TRY(sc->arena.reserve(rows * 128)); PCD_TRY(sc->matches.reserve(2 * off[n_pairs] + 2));
+  PCD_TRY(sc->counts.reserve(n_pairs)); PCD_TRY(sc->dense_off.reserve(2 * ((size_t)n_pairs + 1)));
+  hipStream_t s = nullptr;
+  if (rows) PCD_HIP_TRY(hipMemcpy(sc->arena.p, arena, rows * 128, hipMemcpyHostToDevice));
+  PCD_TRY(pcd_sift_match_batch_device(device, sc->arena.p, first_row, n_images, pairs, n_pairs, max_ratio, max_distance,
+                                      cross_check, sc->matches.p, off.data(), sc->counts.p, s));
+  std::vector<int> cnt((size_t)n_pairs);
+  PCD_HIP_TRY(hipMemcpy(cnt.data(), sc->counts.p, sizeof(int) * (size_t)n_pairs, hipMemcpyDeviceToHost));
+  for (int p = 0; p < n_pairs; ++p) list_offset[p + 1] = list_offset[p] + (uint64_t)cnt[p];
+  const uint64_t total = list_offset[n_pairs];
+  if (total > matches_capacity) {
+    set_error("pcd_sift_match_batch: %llu matches, capacity %llu", (unsigned long long)total, (unsigned long long)matches_capacity);
+    return PCD_ERR_INVALID;
+  }
+  if (total == 0) return PCD_OK;
+  PCD_REQUIRE(matches, "null match buffer");
+  // pack the lists back to back on the device: one download of exactly the matches
+  PCD_TRY(sc->dense.reserve(2 * total));
+  const size_t np1 = (size_t)n_pairs + 1;
+  PCD_HIP_TRY(hipMemcpy(sc->dense_off.p, list_offset, sizeof(uint64_t) * np1, hipMemcpyHostToDevice));
+  PCD_HIP_TRY(hipMemcpy(sc->dense_off.p + np1, off.data(), sizeof(uint64_t) * np1, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_sift_pack_lists, dim3(n_pairs), dim3(256), 0, s, sc->dense_off.p + np1, sc->counts.p,
+                     sc->dense_off.p, sc->matches.p, sc->dense.p);
+  PCD_HIP_TRY(hipGetLastError());
+  PCD_HIP_TRY(hipMemcpy(matches, sc->dense.p, 2 * total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return PCD_OK;
+}
 // ---- matcher handle: two descriptor slots resident on the device (SiftMatchGPU's usage pattern) ----
 }  // extern "C"
 

@@ -104,7 +104,7 @@ ABI_SYMBOLS = [
     "pcd_camera_num_params", "pcd_camera_param_groups", "pcd_ba_create", "pcd_ba_destroy", "pcd_ba_set_parameters", "pcd_ba_set_camera_parameters",
     "pcd_ba_evaluate", "pcd_ba_evaluate_device", "pcd_ba_device_parameters",
     "pcd_profile_enable", "pcd_profile_reset", "pcd_profile_get", "pcd_nn_last_stats",
-    "pcd_sift_match", "pcd_sift_match_device",
+    "pcd_sift_match", "pcd_sift_match_device", "pcd_sift_match_batch", "pcd_sift_match_batch_device",
     "pcd_filter_lidar_outlier_device", "pcd_ba_observation_errors", "pcd_ba_observation_errors_device",
     "pcd_proj_default_options", "pcd_proj_create", "pcd_proj_destroy", "pcd_proj_num_submaps",
     "pcd_proj_last_pairs", "pcd_proj_scale_coeffs", "pcd_proj_set_new_images",
@@ -361,6 +361,49 @@ def sift_match_device(d_d1, n1, d_d2, n2, d_m12, d_m21, d_matches, d_count, max_
                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _check(L.pcd_sift_match_device(device, _ptr(d_d1), n1, _ptr(d_d2), n2, max_ratio, max_distance, int(cross_check),
                                    _ptr(d_m12), _ptr(d_m21), _ptr(d_matches), _ptr(d_count), C.c_void_p(stream)))
+
+
+def _sift_arena(descriptors):
+    """list of [n_i][128] uint8 arrays -> (arena [sum n_i][128], first_row [len + 1] uint64)"""
+    ds = [np.ascontiguousarray(d, np.uint8).reshape(-1, 128) for d in descriptors]
+    first = np.zeros(len(ds) + 1, np.uint64)
+    first[1:] = np.cumsum([d.shape[0] for d in ds])
+    arena = np.concatenate(ds, axis=0) if ds and first[-1] else np.zeros((0, 128), np.uint8)
+    return np.ascontiguousarray(arena), first
+
+
+def sift_match_batch(descriptors, pairs, max_ratio=0.8, max_distance=0.7, cross_check=True, device=0):
+    """SiftFeatureMatcher::Match(image_pairs) (feature/matching.cc:798): `descriptors` = one [n_i][128] uint8 array
+    per image, `pairs` = [P][2] image indices.  Returns a list of P match arrays [M_p][2] uint32, each equal to
+    sift_match(descriptors[a], descriptors[b])."""
+    arena, first = _sift_arena(descriptors)
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    P = pairs.shape[0]
+    off = np.zeros(P + 1, np.uint64)
+    n1 = (first[1:] - first[:-1])[pairs[:, 0]] if P else np.zeros(0, np.uint64)
+    cap = int(n1.sum())
+    m = np.zeros((max(cap, 1), 2), np.uint32)
+    L = lib()
+    L.pcd_sift_match_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                       C.c_float, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
+    _check(L.pcd_sift_match_batch(device, _vp(arena) if arena.shape[0] else None, _vp(first), len(descriptors),
+                                  _vp(pairs) if P else None, P, max_ratio, max_distance, int(cross_check), _vp(m), cap,
+                                  _vp(off)))
+    return [m[int(off[p]):int(off[p + 1])].copy() for p in range(P)]
+
+
+def sift_match_batch_device(d_arena, first_row, pairs, d_matches, match_offset, d_counts, max_ratio=0.8,
+                            max_distance=0.7, cross_check=True, device=0, stream=0):
+    """device form: first_row / pairs / match_offset are numpy (host) arrays, the rest torch device tensors"""
+    first_row = np.ascontiguousarray(first_row, np.uint64)
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    match_offset = np.ascontiguousarray(match_offset, np.uint64)
+    L = lib()
+    L.pcd_sift_match_batch_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                              C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(L.pcd_sift_match_batch_device(device, _ptr(d_arena), _vp(first_row), first_row.shape[0] - 1, _vp(pairs),
+                                         pairs.shape[0], max_ratio, max_distance, int(cross_check), _ptr(d_matches),
+                                         _vp(match_offset), _ptr(d_counts), C.c_void_p(stream)))
 
 
 def filter_lidar_outlier_device(d_points, d_lidar_xyz, d_type, n, max_proj, max_icp, d_erase, device=0, stream=0):

@@ -429,6 +429,28 @@ pcd_status pcd_sift_match_device(int device, const uint8_t* d_desc1, int n1, con
                                  float max_ratio, float max_distance, int cross_check, int32_t* d_m12,
                                  int32_t* d_m21, uint32_t* d_matches, int32_t* d_num_matches, void* stream);
 
+/* Many image pairs in one call: replaces feature/matching.cc:798 SiftFeatureMatcher::Match(image_pairs), which
+ * ExhaustiveFeatureMatcher::Run (:902-960) calls once per block of up to block_size^2 pairs and whose workers
+ * (:358-380 CPU, :403-440 GPU) run MatchSiftFeaturesCPU / MatchSiftFeaturesGPU pair by pair.
+ * All descriptors live in one arena of 128-byte rows: image i owns rows [first_row[i], first_row[i+1]).
+ * `pairs` is n_pairs x {image1, image2}.  Per pair the result is exactly pcd_sift_match(image1, image2).
+ * Device form: first_row / pairs / match_offset are HOST arrays (read before the call returns), d_arena,
+ * d_matches and d_counts device memory.  Pair p's list goes to d_matches + 2 * match_offset[p] and must have
+ * room for n(image1) matches; d_counts[p] = its length.  Three launches per sub-batch of pairs (scores,
+ * finalize, cross check + compaction) on `stream`; the call does not wait for them.
+ * Host form: uploads the arena, returns the lists back to back in `matches` (list p =
+ * matches[2 * list_offset[p] .. 2 * list_offset[p + 1])); PCD_ERR_INVALID if they exceed matches_capacity
+ * (counted in matches; list_offset is still filled so the caller can size the buffer and call again). */
+pcd_status pcd_sift_match_batch_device(int device, const uint8_t* d_arena, const uint64_t* first_row /*[n_images+1]*/,
+                                       int n_images, const uint32_t* pairs /*[n_pairs][2]*/, int n_pairs,
+                                       float max_ratio, float max_distance, int cross_check, uint32_t* d_matches,
+                                       const uint64_t* match_offset /*[n_pairs]*/, int32_t* d_counts /*[n_pairs]*/,
+                                       void* stream);
+pcd_status pcd_sift_match_batch(int device, const uint8_t* arena, const uint64_t* first_row /*[n_images+1]*/, int n_images,
+                                const uint32_t* pairs /*[n_pairs][2]*/, int n_pairs, float max_ratio, float max_distance,
+                                int cross_check, uint32_t* matches, uint64_t matches_capacity,
+                                uint64_t* list_offset /*[n_pairs+1]*/);
+
 /* Matcher object with the shape of lib/SiftGPU's SiftMatchGPU (lib/SiftGPU/SiftGPU.h:268-352) as the reference
  * drives it in feature/sift.cc:1227-1266 MatchSiftFeaturesGPU: two descriptor slots stay on the device, so
  * matching image i against many j uploads i once.  set_descriptors clips num to max_sift like

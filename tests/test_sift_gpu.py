@@ -79,3 +79,78 @@ def test_full_size_pair_properties(gpu):
     assert len(m) == n and np.array_equal(perm[m[:, 1]], m[:, 0])
     mt = gpu.sift_match(d2, d1)
     assert np.array_equal(mt[np.argsort(mt[:, 1])][:, ::-1], m)
+
+
+def _sift_like_images(rng, sizes):
+    """images that really share features: every image is a noisy subset of one pool of SIFT-like descriptors"""
+    pool_n = max(max(sizes), 1) * 2
+    f = rng.random((pool_n, 128), dtype=np.float32) ** 2
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    pool = np.clip(np.round(512 * f), 0, 255).astype(np.int32)
+    out = []
+    for n in sizes:
+        pick = rng.permutation(pool_n)[:n]
+        out.append(np.clip(pool[pick] + rng.integers(-5, 6, (n, 128)), 0, 255).astype(np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("cross,budget", [(True, None), (False, None), (True, "20000")])
+def test_batch_equals_pair_by_pair_and_oracle(gpu, oracle, cross, budget, monkeypatch):
+    """pcd_sift_match_batch (SiftFeatureMatcher::Match(image_pairs), feature/matching.cc:798) over a ragged set of
+    images incl. an empty one, a 1-descriptor one, sizes that are not tile multiples, a pair of an image with
+    itself and repeated pairs: every list equals the single-pair entry and the oracle.  budget = a small bound on
+    the partial-result scratch, so the pair list is cut into many sub-batches (launch sets)."""
+    if budget:
+        monkeypatch.setenv("PCD_SIFT_BATCH_PARTIALS", budget)
+    rng = np.random.default_rng(11)
+    sizes = [300, 0, 1, 129, 700, 128, 515]
+    imgs = _sift_like_images(rng, sizes)
+    pairs = [(a, b) for a in range(len(sizes)) for b in range(len(sizes)) if a <= b] + [(4, 0), (0, 4), (6, 3)]
+    got = gpu.sift_match_batch(imgs, pairs, cross_check=cross)
+    assert len(got) == len(pairs)
+    total = 0
+    for (a, b), g in zip(pairs, got):
+        single = gpu.sift_match(imgs[a], imgs[b], cross_check=cross)
+        assert np.array_equal(g, single), (a, b, len(g), len(single))
+        exp = oracle.sift_match(imgs[a], imgs[b], cross_check=cross)[0]
+        assert np.array_equal(g, exp), (a, b)
+        total += len(g)
+    assert total > 500
+    assert gpu.sift_match_batch(imgs, np.zeros((0, 2), np.uint32)) == []
+
+
+def test_batch_device_form_and_sub_batches(gpu, oracle):
+    """device form with caller-chosen list offsets (3 unused slots between the lists stay untouched)"""
+    rng = np.random.default_rng(12)
+    sizes = [2048, 1500, 2048, 900]
+    imgs = _sift_like_images(rng, sizes)
+    arena = np.concatenate(imgs, axis=0)
+    first = np.zeros(len(sizes) + 1, np.uint64)
+    first[1:] = np.cumsum(sizes)
+    pairs = np.array([(a, b) for a in range(4) for b in range(4) if a != b], np.uint32)
+    n1 = np.array([sizes[a] for a, _ in pairs], np.uint64)
+    off = np.zeros(len(pairs), np.uint64)
+    off[1:] = np.cumsum(n1 + 3)[:-1]          # caller's own layout: 3 unused slots between the lists
+    d_arena = torch.from_numpy(arena).cuda()
+    d_m = torch.full((int(off[-1] + n1[-1]), 2), -1, dtype=torch.int32, device="cuda")
+    d_c = torch.full((len(pairs),), -7, dtype=torch.int32, device="cuda")
+    gpu.sift_match_batch_device(d_arena, first, pairs, d_m, off, d_c)
+    torch.cuda.synchronize()
+    m, c = d_m.cpu().numpy(), d_c.cpu().numpy()
+    for p, (a, b) in enumerate(pairs):
+        exp = oracle.sift_match(imgs[a], imgs[b])[0]
+        assert c[p] == len(exp), (a, b)
+        assert np.array_equal(m[int(off[p]): int(off[p]) + c[p]].astype(np.uint32), exp), (a, b)
+        assert (m[int(off[p]) + int(n1[p]): int(off[p]) + int(n1[p]) + 3] == -1).all() or p == len(pairs) - 1
+
+
+def test_batch_full_size_block(gpu):
+    """a block of the exhaustive matcher at the reference's maximum image size (8192 descriptors,
+    feature/sift.h:59): 6 images -> 15 pairs; lists equal the single-pair entry (itself oracle-checked above)."""
+    rng = np.random.default_rng(13)
+    imgs = _sift_like_images(rng, [8192] * 6)
+    pairs = [(a, b) for a in range(6) for b in range(a + 1, 6)]
+    got = gpu.sift_match_batch(imgs, pairs)
+    for (a, b), g in zip(pairs, got):
+        assert np.array_equal(g, gpu.sift_match(imgs[a], imgs[b])), (a, b)
+    assert sum(len(g) for g in got) > 15 * 2000
