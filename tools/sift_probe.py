@@ -43,3 +43,39 @@ ops = 2.0 * 2 * 128 * n1 * n2          # the tile is computed in both orientatio
 print("pair %d x %d: %.3f ms -> %.0f pairs/s; %d matches" % (n1, n2, ms, 1e3 / ms, int(cnt.item())))
 print("k_sift_scores: %.3f ms, %.1f TOP/s int8 MFMA executed (useful %.1f), dense i8 peak ~5000 TOP/s"
       % (sc, ops / sc / 1e9, ops / 2 / sc / 1e9))
+
+# ---- a block of the exhaustive matcher through the batched entry (SiftFeatureMatcher::Match(image_pairs),
+# feature/matching.cc:798; ExhaustiveMatchingOptions::block_size = 50 images) ----
+for n_img, n_desc in ((16, n1), (50, n1), (50, 2048)):
+    first = np.arange(n_img + 1, dtype=np.uint64) * np.uint64(n_desc)
+    base = np.clip(np.round(512 * f[:n_desc]), 0, 255).astype(np.int32)
+    arena = np.concatenate([np.clip(base[rng.permutation(n_desc)] + rng.integers(-5, 6, (n_desc, 128)), 0, 255).astype(np.uint8)
+                            for _ in range(n_img)], axis=0)
+    pairs = np.array([(a, b) for a in range(n_img) for b in range(a + 1, n_img)], np.uint32)
+    P = len(pairs)
+    off = np.arange(P, dtype=np.uint64) * np.uint64(n_desc)
+    d_arena = torch.from_numpy(arena).cuda()
+    d_m = torch.empty(P * n_desc, 2, dtype=torch.int32, device="cuda")
+    d_c = torch.empty(P, dtype=torch.int32, device="cuda")
+    pcdhip.profile_enable(False)
+    pcdhip.sift_match_batch_device(d_arena, first, pairs, d_m, off, d_c)
+    torch.cuda.synchronize()
+    e0.record()
+    pcdhip.sift_match_batch_device(d_arena, first, pairs, d_m, off, d_c)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    useful = 2.0 * 128 * n_desc * n_desc * P
+    print("batch: %d images x %d descriptors, %d pairs: %.2f ms = %.3f ms/pair -> %.0f pairs/s, %.1f useful TOP/s "
+          "(one S = D1.D2^T per pair; executed 2x), %d matches"
+          % (n_img, n_desc, P, ms, ms / P, P / ms * 1e3, useful / ms / 1e9, int(d_c.sum().item())), flush=True)
+    # the same pairs one call each (what the single-pair entry costs)
+    if P <= 200:
+        torch.cuda.synchronize()
+        e0.record()
+        for a, b in pairs:
+            pcdhip.sift_match_device(d_arena[a * n_desc:(a + 1) * n_desc], n_desc, d_arena[b * n_desc:(b + 1) * n_desc], n_desc,
+                                     m12[:n_desc], m21[:n_desc], mm[:n_desc], cnt)
+        e1.record()
+        torch.cuda.synchronize()
+        print("       pair by pair: %.3f ms/pair" % (e0.elapsed_time(e1) / P))
