@@ -172,13 +172,43 @@ __device__ __forceinline__ void compare_point2(const f32x4 p, const float* qx, c
       : "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
 }
 
+// ONE query against TWO staged points (the odd query of a group): the two points' chains interleave the way the two
+// queries of PCD_CMP_PAIR do.
+__device__ __forceinline__ void compare_query1(const f32x4 pa, const f32x4 pb, const float qx, const float qy,
+                                               const float qz, double& best) {
+  asm("v_mov_b32 v120, %[aw]\n\tv_mov_b32 v118, %[bw]\n\t"
+      "v_sub_f32 v122, %[qx], %[ax]\n\tv_sub_f32 v125, %[qx], %[bx]\n\t"
+      "v_sub_f32 v123, %[qy], %[ay]\n\tv_sub_f32 v126, %[qy], %[by]\n\t"
+      "v_sub_f32 v124, %[qz], %[az]\n\tv_sub_f32 v127, %[qz], %[bz]\n\t"
+      "v_mul_f32 v122, v122, v122\n\tv_mul_f32 v125, v125, v125\n\t"
+      "v_mul_f32 v123, v123, v123\n\tv_mul_f32 v126, v126, v126\n\t"
+      "v_mul_f32 v124, v124, v124\n\tv_mul_f32 v127, v127, v127\n\t"
+      "v_add_f32 v122, v122, v123\n\tv_add_f32 v125, v125, v126\n\t"
+      "v_add_f32 v121, v122, v124\n\tv_add_f32 v119, v125, v127\n\t"
+      "v_min_f64 %[b], %[b], v[120:121]\n\tv_min_f64 %[b], %[b], v[118:119]\n\t"
+      : [b] "+v"(best)
+      : [ax] "v"(pa.x), [ay] "v"(pa.y), [az] "v"(pa.z), [aw] "v"(pa.w), [bx] "v"(pb.x), [by] "v"(pb.y), [bz] "v"(pb.z),
+        [bw] "v"(pb.w), [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz)
+      : "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+}
+
+// the lane's 4 staged points of a tile against the first NQ queries of the group: pairs of queries per point, the
+// odd query (if any) against pairs of points -- exactly NQ compares per point, no padded query slots
 template <int NQ>
-__device__ __forceinline__ void compare_point(const f32x4 p, const float (&qx)[8], const float (&qy)[8],
-                                              const float (&qz)[8], double (&best)[8]) {
-  static_assert(NQ == 2 || NQ == 4 || NQ == 8, "query slots come in pairs");
-  if (NQ == 2) compare_point2(p, qx, qy, qz, best);
-  if (NQ >= 4) compare_point4(p, qx, qy, qz, best);
-  if (NQ == 8) compare_point4(p, qx + 4, qy + 4, qz + 4, best + 4);
+__device__ __forceinline__ void compare_tile(const f32x4 (&p)[4], const float (&qx)[8], const float (&qy)[8],
+                                             const float (&qz)[8], double (&best)[8]) {
+  static_assert(NQ >= 1 && NQ <= 8, "1..8 queries per group");
+  constexpr int E = NQ & ~1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (E >= 4) compare_point4(p[k], qx, qy, qz, best);
+    if (E == 8) compare_point4(p[k], qx + 4, qy + 4, qz + 4, best + 4);
+    if (E == 2 || E == 6) compare_point2(p[k], qx + (E - 2), qy + (E - 2), qz + (E - 2), best + (E - 2));
+  }
+  if (NQ & 1) {
+    compare_query1(p[0], p[1], qx[NQ - 1], qy[NQ - 1], qz[NQ - 1], best[NQ - 1]);
+    compare_query1(p[2], p[3], qx[NQ - 1], qy[NQ - 1], qz[NQ - 1], best[NQ - 1]);
+  }
 }
 
 struct BrickMeta {   // per-group loads issued one group ahead
@@ -380,23 +410,26 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
                      : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
                      : "v"(rd)
                      : "memory");
-        // half-filled groups (cnt <= G/2, wave-uniform) skip the empty query slots
+        // one compare variant per group size (cnt is wave-uniform): no padded query slots
         if (flags & kAblateCompare) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(p[k]));
         } else if (flags & kAblateQuarter) {   // a quarter of the compare work, everything else unchanged
-          compare_point<G>(p[0], qx, qy, qz, best);
+          compare_point4(p[0], qx, qy, qz, best);
+          compare_point4(p[0], qx + 4, qy + 4, qz + 4, best + 4);
 #pragma unroll
           for (int k = 1; k < 4; ++k) asm volatile("" ::"v"(p[k]));
-        } else if (cnt <= G / 4) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) compare_point<G / 4>(p[k], qx, qy, qz, best);
-        } else if (cnt <= G / 2) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) compare_point<G / 2>(p[k], qx, qy, qz, best);
         } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) compare_point<G>(p[k], qx, qy, qz, best);
+          switch (cnt) {   // wave-uniform
+            case 1: compare_tile<1>(p, qx, qy, qz, best); break;
+            case 2: compare_tile<2>(p, qx, qy, qz, best); break;
+            case 3: compare_tile<3>(p, qx, qy, qz, best); break;
+            case 4: compare_tile<4>(p, qx, qy, qz, best); break;
+            case 5: compare_tile<5>(p, qx, qy, qz, best); break;
+            case 6: compare_tile<6>(p, qx, qy, qz, best); break;
+            case 7: compare_tile<7>(p, qx, qy, qz, best); break;
+            default: compare_tile<8>(p, qx, qy, qz, best); break;
+          }
         }
         // (the reads of this buffer have returned -- waited inside the asm block -- before tile t+2's DMAs)
       }
