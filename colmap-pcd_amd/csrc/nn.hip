@@ -374,18 +374,38 @@ namespace pcd {
 // The brick kernel fills the fallback list in per-wavefront chunks (brick_kernel.h kFbChunk); the unused slots of
 // the chunks keep 0xFFFFFFFF.  One pass squeezes them out (wave-aggregated atomics: the order of the dense list is
 // not deterministic, the per-query results do not depend on it) so that k_nn_fallback gets an evenly filled list.
-__global__ void k_fb_compact(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count_ptr,
-                             uint32_t* __restrict__ dense, uint32_t* __restrict__ dense_count) {
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t v = e < *count_ptr ? list[e] : 0xFFFFFFFFu;
-  const bool keep = v != 0xFFFFFFFFu;
-  const unsigned long long m = __ballot(keep);
-  if (m == 0) return;
-  const int lane = threadIdx.x & 63;
-  uint32_t base = 0;
-  if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(dense_count, (uint32_t)__popcll(m));
-  base = __shfl(base, __ffsll((long long)m) - 1);
-  if (keep) dense[base + __popcll(m & ((1ull << lane) - 1))] = v;
+constexpr uint32_t kFbcThreads = 1024, kFbcPer = 4;   // 4096 list slots per workgroup
+__global__ __launch_bounds__(1024) void k_fb_compact(const uint32_t* __restrict__ list,
+                                                     const uint32_t* __restrict__ count_ptr,
+                                                     uint32_t* __restrict__ dense, uint32_t* __restrict__ dense_count) {
+  // one atomic per WORKGROUP of 4096 slots: same-address device-scope atomics serialise at ~10 ns each on this part
+  // (one per wavefront of 64 slots made this pass 45 us for a 390 k-slot list)
+  __shared__ uint32_t s_wave[16], s_base;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t n = *count_ptr;
+  const uint32_t e0 = (blockIdx.x * kFbcThreads + tid) * kFbcPer;
+  if (blockIdx.x * kFbcThreads * kFbcPer >= n) return;   // whole workgroup past the end
+  uint32_t v[kFbcPer], cnt = 0;
+  if (e0 + kFbcPer <= n) {
+    const uint4 q = *reinterpret_cast<const uint4*>(list + e0);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  } else {
+#pragma unroll
+    for (uint32_t k = 0; k < kFbcPer; ++k) v[k] = e0 + k < n ? list[e0 + k] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kFbcPer; ++k) cnt += v[k] != 0xFFFFFFFFu ? 1u : 0u;
+  const uint32_t inc = wave_scan_add_u32(cnt);
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (uint32_t w = 0; w < kFbcThreads / 64; ++w) { before += w < wave ? s_wave[w] : 0u; total += s_wave[w]; }
+  if (tid == 0) s_base = total ? atomicAdd(dense_count, total) : 0u;
+  __syncthreads();
+  uint32_t pos = s_base + before + inc - cnt;
+#pragma unroll
+  for (uint32_t k = 0; k < kFbcPer; ++k)
+    if (v[k] != 0xFFFFFFFFu) dense[pos++] = v[k];
 }
 
 // --------------------------------------------------------- exact fallback ---
@@ -569,8 +589,11 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     // rocPRIM's default takes its merge sort (log2(Q / block) launches) up to 2^20 items: Onesweep above 256 k (below that its ~25 us per digit pass cost more than the merge passes)
 // (Onesweep with 10-12-bit digits -- two passes over the 23-bit brick ids instead of three -- does not fit:
     //  rocPRIM's block ranking then needs 192 KiB - 2 MiB of LDS)
+#ifndef PCD_SORT_MERGE_LIMIT
+#define PCD_SORT_MERGE_LIMIT 262144
+#endif
     using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                               rocprim::default_config, 262144>;
+                                               rocprim::default_config, PCD_SORT_MERGE_LIMIT>;
     PCD_HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tb, k0, k1, v0, v1, (unsigned)Q, 0u, end_bit, s));
     PCD_TRY(sc->tmp.reserve(tb));
     PCD_HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(sc->tmp.p, tb, k0, k1, v0, v1, (unsigned)Q, 0u, end_bit, s));
@@ -589,7 +612,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   {
     ScopedKernelTimer t("nn_fallback", s);
     PCD_TRY(sc->fb_dense.reserve(Q));
-    hipLaunchKernelGGL(k_fb_compact, dim3(div_up(fb_cap, 256)), dim3(256), 0, s, sc->fb_list.p,
+    hipLaunchKernelGGL(k_fb_compact, dim3(div_up(fb_cap, kFbcThreads * kFbcPer)), dim3(kFbcThreads), 0, s, sc->fb_list.p,
                        &sc->counters.p->fb_count, sc->fb_dense.p, &sc->counters.p->pad[0]);
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), 256 * 8);
     hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, g, c->pyr, c->sorted.p, c->cell_start.p,
