@@ -452,10 +452,12 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
     const unsigned long long um = __ballot(unproven);
     if (um) {
       // the wavefront appends to the fallback list inside chunks of kFbChunk slots it reserves with ONE returning
-      // atomic each (an atomic per item exposed its latency on every fourth item); unused slots of a chunk keep
-      // the 0xFFFFFFFF the list was filled with; k_fb_compact squeezes them out
+      // atomic each (an atomic per item exposed its latency on every fourth item); the slots of a chunk it does not
+      // use get 0xFFFFFFFF when the chunk is left (here and at the end of the kernel): the list needs no memset;
+      // k_fb_compact squeezes the sentinels out
       const uint32_t k = (uint32_t)__popcll(um);
       if (k > fb_left) {   // wave-uniform
+        if (lane < (int)fb_left) fb_list[fb_base + lane] = 0xFFFFFFFFu;
         uint32_t nb = 0;
         if (lane == 0) nb = atomicAdd(&ctr->fb_count, (uint32_t)kFbChunk);
         fb_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
@@ -468,6 +470,7 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
     if (collect_stats) { st_staged += T; st_pairs += (unsigned long long)T * cnt; st_groups += 1; }
     it0 = it1; it1 = it2; m0 = m1;
   }
+  if (lane < (int)fb_left) fb_list[fb_base + lane] = 0xFFFFFFFFu;   // rest of the last chunk
   if (collect_stats && lane == 0) {
     atomicAdd(&ctr->staged_points, st_staged);
     atomicAdd(&ctr->pair_evals, st_pairs);
