@@ -111,6 +111,7 @@ struct PinnedBuf {
 struct Profiler {
   static Profiler& get();
   bool enabled = false;
+  std::string only;   // non-empty: time just the scope of this name (pcd_profile_only)
   struct Rec { std::string name; hipEvent_t a, b; };
   std::vector<Rec> pending;
   struct Tot { std::string name; uint64_t launches; double ms; };
@@ -126,6 +127,7 @@ struct ScopedKernelTimer {
   hipStream_t s;
   bool on;
   ScopedKernelTimer(const char* name, hipStream_t stream) : s(stream), on(Profiler::get().enabled) {
+    if (on && !Profiler::get().only.empty() && Profiler::get().only != name) on = false;
     if (on) Profiler::get().begin(name, s);
   }
   ~ScopedKernelTimer() {

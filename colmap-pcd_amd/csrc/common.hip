@@ -105,6 +105,10 @@ pcd_status pcd_profile_enable(int on) {
   pcd::Profiler::get().enabled = on != 0;
   return PCD_OK;
 }
+pcd_status pcd_profile_only(const char* scope) {
+  pcd::Profiler::get().only = scope ? scope : "";
+  return PCD_OK;
+}
 pcd_status pcd_profile_reset(void) {
   pcd::Profiler::get().reset();
   return PCD_OK;

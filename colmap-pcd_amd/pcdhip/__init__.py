@@ -103,7 +103,7 @@ ABI_SYMBOLS = [
     "pcd_associate_from_payload_device", "pcd_search_range_schedule",
     "pcd_camera_num_params", "pcd_camera_param_groups", "pcd_ba_create", "pcd_ba_destroy", "pcd_ba_set_parameters", "pcd_ba_set_camera_parameters",
     "pcd_ba_evaluate", "pcd_ba_evaluate_device", "pcd_ba_device_parameters",
-    "pcd_profile_enable", "pcd_profile_reset", "pcd_profile_get", "pcd_nn_last_stats",
+    "pcd_profile_enable", "pcd_profile_only", "pcd_profile_reset", "pcd_profile_get", "pcd_nn_last_stats",
     "pcd_sift_match", "pcd_sift_match_device", "pcd_sift_match_batch", "pcd_sift_match_batch_device",
     "pcd_filter_lidar_outlier_device", "pcd_ba_observation_errors", "pcd_ba_observation_errors_device",
     "pcd_proj_default_options", "pcd_proj_create", "pcd_proj_destroy", "pcd_proj_num_submaps",
@@ -520,6 +520,13 @@ def set_nn_tuning(brick_cells=0, halo_cells=-1, collect_stats=0):
 
 def profile_enable(on=True):
     lib().pcd_profile_enable(int(on))
+
+
+def profile_only(scope=None):
+    """time just one scope (None: all of them)"""
+    L = lib()
+    L.pcd_profile_only.argtypes = [C.c_char_p]
+    L.pcd_profile_only(scope.encode() if scope else None)
 
 
 def profile_reset():

@@ -473,6 +473,8 @@ typedef struct {
   double total_ms;
 } pcd_kernel_time;
 pcd_status pcd_profile_enable(int on);
+pcd_status pcd_profile_only(const char* scope);   /* time just this scope (NULL / "": all): two HIP events per timed
+                                                      scope cost a few microseconds of stream time each */
 pcd_status pcd_profile_reset(void);
 /* fills up to cap entries, returns the number of distinct kernels in *count (syncs the device) */
 pcd_status pcd_profile_get(pcd_kernel_time* entries, int cap, int* count);

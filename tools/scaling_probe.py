@@ -47,11 +47,13 @@ for N in Ns:
         ba.evaluate_device(dict(cost=cr), stream)
     for _ in range(5): step()
     torch.cuda.synchronize()
-    pcdhip.profile_enable(True); pcdhip.profile_reset()
     t0 = time.perf_counter()
     for _ in range(20): step()
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / 20
+    pcdhip.profile_enable(True); pcdhip.profile_reset()   # per-kernel breakdown in its own pass (events cost stream time)
+    for _ in range(20): step()
+    torch.cuda.synchronize()
     prof = pcdhip.profile_get(); pcdhip.profile_enable(False)
     t1 = t1 or t
     print("N=%d: per-rank step %.3f ms (Q=%d, obs=%d) -> speed-up before collectives %.2fx   %s" % (
