@@ -409,6 +409,11 @@ __global__ __launch_bounds__(1024) void k_fb_compact(const uint32_t* __restrict_
 }
 
 // --------------------------------------------------------- exact fallback ---
+#ifndef PCD_FB_LOADS
+#define PCD_FB_LOADS 4
+#endif
+constexpr int kFbLoads = PCD_FB_LOADS;   // point loads in flight per lane in a leaf scan step
+
 // scan the point range [s,e): lanes stride over it
 __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, uint32_t s, uint32_t e, float qx,
                                            float qy, float qz, uint64_t& lane_best) {
@@ -517,10 +522,10 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
           o[k] = (uint32_t)__builtin_amdgcn_readlane((int)roff, k);
           dd[k] = (uint32_t)__builtin_amdgcn_readlane((int)rs, k) - o[k];
         }
-        for (uint32_t base = 0; base < Tb; base += 256) {
-          float4 p[4];
+        for (uint32_t base = 0; base < Tb; base += 64 * kFbLoads) {
+          float4 p[kFbLoads];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < kFbLoads; ++k) {
             uint32_t gi = base + k * 64 + lane;
             gi = gi < Tb ? gi : Tb - 1;
             // empty ranges share their offset with the next one: test from the last range down
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
             p[k] = sorted[gi + dl];
           }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < kFbLoads; ++k) {
             if (base + k * 64 + lane < Tb) {
               const float d = l2_simple3(qx, qy, qz, p[k].x, p[k].y, p[k].z);
               const uint64_t key = make_key(d, __float_as_uint(p[k].w));
