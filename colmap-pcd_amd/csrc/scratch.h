@@ -31,6 +31,21 @@ struct QueryScratch {
   PinnedBuf<double> h_q, h_mr;
   PinnedBuf<pcd_assoc_hit> h_hits;
   PinnedBuf<uint32_t> h_count;
+  // staged host path: copies in / compute / copies out on their own streams, chunk by chunk (assoc.hip)
+  static constexpr int kStageChunks = 4;
+  hipStream_t st_in = nullptr, st_comp = nullptr, st_out = nullptr, st_cnt = nullptr;
+  hipEvent_t ev_in[kStageChunks] = {}, ev_comp[kStageChunks] = {}, ev_cnt[kStageChunks] = {};
+  ~QueryScratch() {
+    for (int k = 0; k < kStageChunks; ++k) {
+      if (ev_in[k]) (void)hipEventDestroy(ev_in[k]);
+      if (ev_comp[k]) (void)hipEventDestroy(ev_comp[k]);
+      if (ev_cnt[k]) (void)hipEventDestroy(ev_cnt[k]);
+    }
+    if (st_in) (void)hipStreamDestroy(st_in);
+    if (st_comp) (void)hipStreamDestroy(st_comp);
+    if (st_out) (void)hipStreamDestroy(st_out);
+    if (st_cnt) (void)hipStreamDestroy(st_cnt);
+  }
   DevBuf<pcd_assoc_hit> d_hits;
   DevBuf<uint32_t> hit_pos, hit_count;
 };

@@ -143,11 +143,13 @@ def test_associate_device_ignores_foreign_keys(gpu, oracle):
 @pytest.mark.parametrize("mode", [0, 2])
 def test_staged_host_path(gpu, oracle, mode):
     """pcd_assoc_staging + pcd_associate_staged (pinned staging, device-side compaction): the records are exactly the
-    accepted rows of pcd_associate, in ascending query order; scalar and per-point range; empty batch; re-use."""
+    accepted rows of pcd_associate, in ascending query order; scalar and per-point range; empty batch; re-use.
+    Batches of >= 200 k queries move through the three-stream, two-chunk pipeline (an odd count, so the chunks differ
+    in length), smaller ones through one stream."""
     xyz, nrm = synth.cloud_planes(60000, seed=20240601, patches=20)
     nrm[::97] = 0.0
     c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
-    for Q, seed in ((70000, 1), (5000, 2)):        # large batch (grid path), then a smaller one in the same buffers
+    for Q, seed in ((70000, 1), (5000, 2), (250001, 3), (70000, 4)):   # grid path, small, two chunks, re-use after
         q = synth.queries(xyz, Q, seed=seed)
         mr = synth.max_range_schedule(Q, seed=seed)
         full = c.associate(q, None if mode == 2 else mr, mode)
