@@ -181,7 +181,11 @@ def main():
     Q = qhi - qlo
     my_scene = scene if world == 1 else pdist.shard_tracks(scene, rank, world)[0]
     cloud = pcdhip.Cloud(xyz, nrm, device=local_rank, raw_lidar_frame=False)
+    torch.cuda.synchronize()
+    t_create = time.perf_counter()
     ba = pcdhip.BA(**my_scene, device=local_rank)
+    torch.cuda.synchronize()
+    ba_create_ms = (time.perf_counter() - t_create) * 1e3   # upload + index building (host counting sorts, device gathers)
     I, P, O, L = ba.I, ba.P, ba.O, ba.L
     Ptot, Otot, Ltot = scene["points"].shape[0], len(scene["obs_image"]), len(scene["lidar_point"])
 
@@ -271,7 +275,7 @@ def main():
         t_raw = timed(raw_step, a.steps, sync)
         t_nn = timed(nn_step, a.steps, sync)
         t_ba = timed(ba_step, a.steps, sync)
-        extras.update(ba_raw_iter_ms=t_raw * 1e3, nn_wall_ms=t_nn * 1e3, ba_wall_ms=t_ba * 1e3)
+        extras.update(ba_raw_iter_ms=t_raw * 1e3, nn_wall_ms=t_nn * 1e3, ba_wall_ms=t_ba * 1e3, ba_create_ms=ba_create_ms)
         del raw, res_only
         # ---- what the call sites need: the search bounded by each query's gate (PCD_GATE_BOUNDED_SEARCH) --------
         # same recorded associations, same field values (tests/test_assoc_gpu.py::test_gate_bounded_search); the

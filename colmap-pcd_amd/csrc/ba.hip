@@ -774,6 +774,45 @@ static pcd_status upload(DevBuf<T>& b, const T* src, size_t n) {
   return PCD_OK;
 }
 
+// ---- derived layouts, filled on the device from the uploaded observation arrays -----------------------------
+// The host only sorts indices (counting sorts); the 16-byte observation payloads never make a second trip over PCIe
+// and are never gathered by a host loop (pcd_ba_create: 220 -> see DESIGN 4.3 for the bench scene).
+// sliced ELL: thread = (slice, lane): track p = order[slice*64 + lane], its j-th observation goes to slot
+// slice_start[slice] + 64 j + lane
+__global__ void k_ba_fill_sell(const int* __restrict__ order, const uint32_t* __restrict__ slice_start,
+                               const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_list,
+                               const int* __restrict__ obs_image, const double* __restrict__ obs_xy, int nslices,
+                               int* __restrict__ sell_img, double* __restrict__ sell_xy) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int slice = t >> 6, lane = t & 63;
+  if (slice >= nslices) return;
+  const uint32_t s0 = slice_start[slice], width = (slice_start[slice + 1] - s0) >> 6;
+  const int p = order[t];
+  const uint32_t b = p >= 0 ? pt_start[p] : 0u, len = p >= 0 ? pt_start[p + 1] - b : 0u;
+  for (uint32_t j = 0; j < width; ++j) {
+    const size_t slot = (size_t)s0 + 64 * (size_t)j + lane;
+    if (j < len) {
+      const uint32_t o = pt_list[b + j];
+      sell_img[slot] = obs_image[o];
+      const double2 xy = *reinterpret_cast<const double2*>(obs_xy + 2 * (size_t)o);
+      *reinterpret_cast<double2*>(sell_xy + 2 * slot) = xy;
+    } else {
+      sell_img[slot] = -1;   // padding of a shorter track
+      *reinterpret_cast<double2*>(sell_xy + 2 * slot) = make_double2(0.0, 0.0);
+    }
+  }
+}
+// image-major copies: e-th observation of the image-major order = observation img_obs[e] of the caller's order
+__global__ void k_ba_fill_image_major(const uint32_t* __restrict__ img_obs, const int* __restrict__ obs_point,
+                                      const double* __restrict__ obs_xy, uint64_t O, int* __restrict__ img_pt,
+                                      double* __restrict__ img_xy) {
+  const uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (e >= O) return;
+  const uint32_t o = img_obs[e];
+  img_pt[e] = obs_point[o];
+  *reinterpret_cast<double2*>(img_xy + 2 * e) = *reinterpret_cast<const double2*>(obs_xy + 2 * (size_t)o);
+}
+
 // stable counting sort of element ids by key -> CSR (start[nkeys+1], list[n])
 static void build_csr(const int32_t* key, uint64_t n, int nkeys, std::vector<uint32_t>& start,
                       std::vector<uint32_t>& list) {
@@ -849,54 +888,48 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
   // ---- per-track sliced ELL in order of track length ----
   build_csr(d->obs_point, b->O, b->P, st, li);
   {
-    std::vector<int> order(b->P);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return st[a + 1] - st[a] < st[c + 1] - st[c]; });
+    // tracks in ascending order of length, ties in ascending point id: a counting sort (lengths are small numbers)
+    uint32_t maxlen = 0;
+    for (int p = 0; p < b->P; ++p) maxlen = std::max(maxlen, st[p + 1] - st[p]);
+    std::vector<uint32_t> bucket((size_t)maxlen + 2, 0);
+    for (int p = 0; p < b->P; ++p) bucket[(size_t)(st[p + 1] - st[p]) + 1]++;
+    for (size_t k = 1; k < bucket.size(); ++k) bucket[k] += bucket[k - 1];
     const int nslices = (b->P + 63) / 64;
     b->nslices = nslices;
-    order.resize((size_t)nslices * 64, -1);
+    std::vector<int> order((size_t)nslices * 64, -1);
+    for (int p = 0; p < b->P; ++p) order[bucket[st[p + 1] - st[p]]++] = p;
     std::vector<uint32_t> slice_start(nslices + 1, 0);
     for (int s = 0; s < nslices; ++s) {
+      // ascending lengths: the longest track of a slice is its last real one
       uint32_t mx = 0;
-      for (int l = 0; l < 64; ++l) {
+      for (int l = 63; l >= 0; --l) {
         const int p = order[(size_t)s * 64 + l];
-        if (p >= 0) mx = std::max(mx, st[p + 1] - st[p]);
+        if (p >= 0) { mx = st[p + 1] - st[p]; break; }
       }
       slice_start[s + 1] = slice_start[s] + mx * 64;
     }
     const size_t nslots = slice_start[nslices];
-    std::vector<int> sell_img(std::max<size_t>(nslots, 1), -1);
-    std::vector<double> sell_xy(std::max<size_t>(2 * nslots, 2), 0.0);
-    for (int s = 0; s < nslices; ++s)
-      for (int l = 0; l < 64; ++l) {
-        const int p = order[(size_t)s * 64 + l];
-        if (p < 0) continue;
-        for (uint32_t j = 0; j < st[p + 1] - st[p]; ++j) {
-          const uint32_t o = li[st[p] + j];
-          const size_t slot = (size_t)slice_start[s] + 64 * (size_t)j + l;
-          sell_img[slot] = d->obs_image[o];
-          sell_xy[2 * slot] = d->obs_xy[2 * (size_t)o];
-          sell_xy[2 * slot + 1] = d->obs_xy[2 * (size_t)o + 1];
-        }
-      }
     UP(pt_order, order.data(), order.size());
     UP(slice_start, slice_start.data(), slice_start.size());
-    UP(sell_img, sell_img.data(), sell_img.size());
-    UP(sell_xy, sell_xy.data(), sell_xy.size());
+    // the track CSR is only needed to fill the ELL: it borrows the buffers of the lidar CSR uploaded right after
+    UP(pt_lidar_start, st.data(), st.size()); UP(pt_lidar_list, li.data(), li.size());
+    pcd_status sa = b->sell_img.reserve(std::max<size_t>(nslots, 1));
+    if (sa == PCD_OK) sa = b->sell_xy.reserve(std::max<size_t>(2 * nslots, 2));
+    if (sa != PCD_OK) return fail(sa);
+    if (nslots)
+      hipLaunchKernelGGL(k_ba_fill_sell, dim3(div_up((size_t)nslices * 64, 256)), dim3(256), 0, nullptr, b->pt_order.p,
+                         b->slice_start.p, b->pt_lidar_start.p, b->pt_lidar_list.p, b->obs_image.p, b->obs_xy.p, nslices,
+                         b->sell_img.p, b->sell_xy.p);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
+      set_error("pcd_ba_create: filling the per-track layout failed");
+      return fail(PCD_ERR_HIP);
+    }
   }
   build_csr(d->lidar_point, b->L, b->P, st, li);
   UP(pt_lidar_start, st.data(), st.size()); UP(pt_lidar_list, li.data(), li.size());
   // ---- per-image contiguous copies ----
   build_csr(d->obs_image, b->O, b->I, st, li);
   {
-    std::vector<int> img_pt(std::max<size_t>(b->O, 1));
-    std::vector<double> img_xy(std::max<size_t>(2 * b->O, 2));
-    for (uint64_t e = 0; e < b->O; ++e) {
-      const uint32_t o = li[e];
-      img_pt[e] = d->obs_point[o];
-      img_xy[2 * e] = d->obs_xy[2 * (size_t)o];
-      img_xy[2 * e + 1] = d->obs_xy[2 * (size_t)o + 1];
-    }
     UP(img_obs_start, st.data(), st.size());
     {  // segments of <= kImgSeg observations, never spanning two images (an image without observations has none)
       std::vector<uint32_t> seg_img, seg_begin, img_seg_start(b->I + 1, 0);
@@ -918,8 +951,16 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
       UP(cam_img_list, cli.data(), cli.size());
     }
     UP(img_obs, li.data(), li.size());
-    UP(img_pt, img_pt.data(), img_pt.size());
-    UP(img_xy, img_xy.data(), img_xy.size());
+    pcd_status sa = b->img_pt.reserve(std::max<size_t>(b->O, 1));
+    if (sa == PCD_OK) sa = b->img_xy.reserve(std::max<size_t>(2 * b->O, 2));
+    if (sa != PCD_OK) return fail(sa);
+    if (b->O)
+      hipLaunchKernelGGL(k_ba_fill_image_major, dim3(div_up(b->O, 256)), dim3(256), 0, nullptr, b->img_obs.p,
+                         b->obs_point.p, b->obs_xy.p, b->O, b->img_pt.p, b->img_xy.p);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
+      set_error("pcd_ba_create: filling the image-major layout failed");
+      return fail(PCD_ERR_HIP);
+    }
   }
 #undef UP
   pcd_status s1 = b->cost_partial.reserve(std::max<size_t>(div_up((size_t)b->nslices * 64, 256), div_up(b->O + b->L, 256)) + 1);
