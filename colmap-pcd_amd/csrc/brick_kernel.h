@@ -309,10 +309,14 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
     float qx[G], qy[G], qz[G];   // wave-uniform, but held in VGPRs: SGPR operands halve the VALU rate (compare_point)
 #pragma unroll
     for (int k = 0; k < G; ++k) {
-      const int src = k < (int)cnt ? k : 0;  // empty slots repeat query 0; their results are not written
-      asm volatile("v_mov_b32 %0, %1" : "=v"(qx[k]) : "s"(readlane_f(m0.q.x, src)));
-      asm volatile("v_mov_b32 %0, %1" : "=v"(qy[k]) : "s"(readlane_f(m0.q.y, src)));
-      asm volatile("v_mov_b32 %0, %1" : "=v"(qz[k]) : "s"(readlane_f(m0.q.z, src)));
+      // slots >= cnt stay unset: the compare variant of this group size never reads them (wave-uniform skip)
+      if (k == 0 || k < (int)cnt) {
+        asm volatile("v_mov_b32 %0, %1" : "=v"(qx[k]) : "s"(readlane_f(m0.q.x, k)));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(qy[k]) : "s"(readlane_f(m0.q.y, k)));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(qz[k]) : "s"(readlane_f(m0.q.z, k)));
+      } else {
+        qx[k] = qy[k] = qz[k] = 0.f;
+      }
     }
     int c0[3], c1[3];
     brick_region(g, b, it0, c0, c1);
