@@ -248,19 +248,41 @@ __global__ __launch_bounds__(256) void k_proj_splat(const ProjImageDev* __restri
       const float nrm = sqrtf(xc * xc + (yc * yc + zc * zc));
       const uint64_t key = ((uint64_t)__float_as_uint(nrm) << 32) | pos;
       const int wlo = ulo >> 5, whi = uhi >> 5;
-      for (int v = vlo; v <= vhi; ++v) {
-        const uint32_t* row = bm + (uint64_t)v * RW;
-        for (int w = wlo; w <= whi; ++w) {
-          uint32_t bits = row[w];
-          if (!bits) continue;
-          if (w == wlo) bits &= 0xFFFFFFFFu << (ulo & 31);
-          if (w == whi) bits &= 0xFFFFFFFFu >> (31 - (uhi & 31));
-          while (bits) {
-            const int b = __builtin_ctz(bits);
-            bits &= bits - 1;
-            uint64_t* slot = zb + (uint64_t)v * W + (w * 32 + b);
-            if (*(volatile uint64_t*)slot > key) atomicMin((unsigned long long*)slot, (unsigned long long)key);
+      auto hit_word = [&](uint32_t bits, int w, int v) {
+        if (!bits) return;
+        if (w == wlo) bits &= 0xFFFFFFFFu << (ulo & 31);
+        if (w == whi) bits &= 0xFFFFFFFFu >> (31 - (uhi & 31));
+        while (bits) {
+          const int b = __builtin_ctz(bits);
+          bits &= bits - 1;
+          uint64_t* slot = zb + (uint64_t)v * W + (w * 32 + b);
+          if (*(volatile uint64_t*)slot > key) atomicMin((unsigned long long*)slot, (unsigned long long)key);
+        }
+      };
+      if (whi - wlo <= 1) {
+        // the usual case, a splat one or two bitmap words wide: the words of four rows are fetched together (clamped
+        // row index, no branch around the loads) before any of them is looked at -- one round trip per four rows
+        // instead of one per row
+        const bool two = whi != wlo;
+        for (int v = vlo; v <= vhi; v += 4) {
+          uint32_t b0[4], b1[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t* row = bm + (uint64_t)min(v + k, vhi) * RW;
+            b0[k] = row[wlo];
+            b1[k] = row[whi];
           }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (v + k > vhi) break;
+            hit_word(b0[k], wlo, v + k);
+            if (two) hit_word(b1[k], whi, v + k);
+          }
+        }
+      } else {
+        for (int v = vlo; v <= vhi; ++v) {
+          const uint32_t* row = bm + (uint64_t)v * RW;
+          for (int w = wlo; w <= whi; ++w) hit_word(row[w], w, v);
         }
       }
     }
