@@ -192,6 +192,11 @@ __global__ void k_proj_cull(const ProjImageDev* __restrict__ imgs, const int4* _
 }
 
 // One wavefront per surviving (image, submap); lanes stride over the submap's points.
+#ifndef PCD_SPLAT_ROWS
+#define PCD_SPLAT_ROWS 4
+#endif
+constexpr int kSplatRows = PCD_SPLAT_ROWS;   // bitmap rows fetched together by a lane of k_proj_splat
+                                             // (1 / 4 / 8 / 16 rows: 1.46 / 1.06 / 1.12 / 1.20 ms on tools/proj_probe.py)
 __global__ __launch_bounds__(256) void k_proj_splat(const ProjImageDev* __restrict__ imgs,
                                                     const uint2* __restrict__ items,
                                                     const unsigned* __restrict__ n_items,
@@ -264,16 +269,16 @@ __global__ __launch_bounds__(256) void k_proj_splat(const ProjImageDev* __restri
         // row index, no branch around the loads) before any of them is looked at -- one round trip per four rows
         // instead of one per row
         const bool two = whi != wlo;
-        for (int v = vlo; v <= vhi; v += 4) {
-          uint32_t b0[4], b1[4];
+        for (int v = vlo; v <= vhi; v += kSplatRows) {
+          uint32_t b0[kSplatRows], b1[kSplatRows];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < kSplatRows; ++k) {
             const uint32_t* row = bm + (uint64_t)min(v + k, vhi) * RW;
             b0[k] = row[wlo];
             b1[k] = row[whi];
           }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < kSplatRows; ++k) {
             if (v + k > vhi) break;
             hit_word(b0[k], wlo, v + k);
             if (two) hit_word(b1[k], whi, v + k);
