@@ -313,17 +313,28 @@ __global__ __launch_bounds__(256) void k_brick_emit(const uint32_t* __restrict__
   bool flag[4];
   brick_tile<G>(keys, Q, nbricks, blockIdx.x, key, ex, flag, &total, s_wave, s_left);
   const uint32_t j0 = blockIdx.x * kBkTile + tid * 4;
+  // the four positions of a thread: all loads of a stage are issued before any is used (the dependent chain
+  // vals -> qf4 / keys_in would otherwise be walked four times in a row)
+  uint32_t v[4];
+  float4 q[4];
+  uint64_t kin[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = j0 + k < Q ? vals[j0 + k] : 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool in = j0 + k < Q && key[k] < nbricks;
+    q[k] = in ? qf4[v[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // the key the query came with (a plain query comes with kKeyInit: no gather)
+    kin[k] = (in && keys_in) ? keys_in[v[k]] : kKeyInit;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t j = j0 + k;
     if (j >= Q) break;
-    const uint32_t v = vals[j];
     if (key[k] < nbricks) {
-      float4 q = qf4[v];
-      q.w = __uint_as_float(v);          // brick-sorted query record {x, y, z, bits(query id)}
-      qsorted[j] = q;
-      // the key the query came with, in the same order (a plain query comes with kKeyInit: no gather)
-      ksorted[j] = keys_in ? keys_in[v] : kKeyInit;
+      q[k].w = __uint_as_float(v[k]);          // brick-sorted query record {x, y, z, bits(query id)}
+      qsorted[j] = q[k];
+      ksorted[j] = kin[k];
       if (flag[k]) {
         uint32_t cnt = 1;
         while (cnt < (uint32_t)G && j + cnt < Q && keys[j + cnt] == key[k]) ++cnt;
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(256) void k_brick_emit(const uint32_t* __restrict__
         items[tile_off + ex[k]] = make_uint4(j, bx, by, bz | (cnt << 28));
       }
     } else if (key[k] == nbricks) {
-      fb_list[atomicAdd(&ctr->fb_count, 1u)] = v;   // outside the grid: straight to the exact fallback
+      fb_list[atomicAdd(&ctr->fb_count, 1u)] = v[k];   // outside the grid: straight to the exact fallback
     }
   }
   if (blockIdx.x == gridDim.x - 1 && tid == 0) ctr->nitems = tile_off + total;
