@@ -590,7 +590,9 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   PCD_TRY(sc->qsorted.reserve(Q));
   PCD_TRY(sc->ksorted.reserve(Q));
   // fallback list: one slot per query + the chunk slack of every wavefront of the brick kernel (brick_kernel.h)
-  const size_t fb_cap = Q + (size_t)256 * g_brick_blocks_per_cu * 4 * kFbChunk;
+  // A wavefront leaves a chunk when the next item's unproven queries (<= 8) do not fit: at most 7 of 64 slots stay
+  // unused per chunk, so the reserved slots are <= used * 64 / 57 + one chunk per wavefront, used <= Q.
+  const size_t fb_cap = Q + Q / 8 + 8 + (size_t)256 * g_brick_blocks_per_cu * 4 * kFbChunk;
   PCD_TRY(sc->fb_list.reserve(fb_cap));   // no memset: every reserved slot is written (a query id or the sentinel)
   PCD_TRY(sc->bk_keys.reserve(2 * Q));
   PCD_TRY(sc->bk_vals.reserve(2 * Q));

@@ -170,6 +170,26 @@ def test_midsize_vs_kdtree_oracle_and_gpu_bruteforce(gpu, oracle):
     c.close()
 
 
+def test_every_query_unproven_inside_the_grid(gpu, oracle):
+    """two slabs 40 m apart and 300 k queries in the empty space between them: inside the grid, nothing within any
+    brick's halo, so EVERY query goes through the brick kernel's chunked fallback list (chunks left with unused
+    slots, list capacity, squeeze) and is answered by the exact fallback.  Bit-exact against the CPU KD-tree."""
+    rng = np.random.default_rng(17)
+    a = rng.random((150_000, 3)).astype(np.float32) * np.array([0.5, 30.0, 30.0], np.float32)
+    b = a.copy(); b[:, 0] += 40.0
+    xyz = np.concatenate([a, b]); nrm = np.zeros_like(xyz); nrm[:, 0] = 1.0
+    q = rng.random((300_000, 3)) * np.array([30.0, 30.0, 30.0]) + np.array([5.0, 0.0, 0.0])
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    got = c.nn(q, gpu.NN_GRID)
+    st = c.last_stats()
+    kd = oracle.KDTree(xyz)
+    sel = rng.choice(q.shape[0], 30000, replace=False)
+    gi, gd, gf = got
+    _check_exact((gi[sel], gd[sel], gf[sel]), kd.query(q[sel]), "all-unproven grid path vs cpu kd-tree")
+    assert gf.all()
+    c.close()
+
+
 @pytest.mark.parametrize("N,Q", [(10_000_000, 1_000_000), (20_000_000, 2_000_000)],
                          ids=["config M: 10M cloud / 1M queries", "config C: 20M cloud / 2M queries"])
 def test_full_size_properties(gpu, N, Q):
