@@ -115,6 +115,20 @@ __global__ void k_prepare_refine(const double* __restrict__ q, uint64_t Q, const
 // the impossible index at the end means "nothing within the gate" (-> PCD_KEY_NONE, type 0, as the reference's gate
 // decides).  bound = float >= R^2 (1 + 1e-5): the float distance of any point that passes the double-precision gate
 // is below it.  NaN range: the reference's `dist > range` is false, nothing is rejected -> unbounded.
+__device__ __forceinline__ uint64_t bounded_init_key(double R) {
+  uint64_t k = kKeyInit;
+  if (R == R) {   // not NaN
+    const double b = R < 0.0 ? 0.0 : R * R * (1.0 + 1e-5);
+    float bf = (float)b;
+    if ((double)bf < b) bf = nextafterf(bf, INFINITY);
+    if (bf < FLT_MAX) k = ((uint64_t)__float_as_uint(bf) << 32) | 0xFFFFFFFFull;
+  }
+  return k;
+}
+// keys still at their initial value (kKeyInit, or a bound with the impossible index) mean "nothing found"
+__device__ __forceinline__ uint64_t finalized_key(uint64_t k) {
+  return (k == kKeyInit || (uint32_t)k == 0xFFFFFFFFu) ? PCD_KEY_NONE : k;
+}
 __global__ void k_prepare_bounded(const double* __restrict__ q, uint64_t Q, const double* __restrict__ max_range,
                                   uint64_t mr_count, double fixed_range, float4* __restrict__ qf4,
                                   uint64_t* __restrict__ keys) {
@@ -123,23 +137,14 @@ __global__ void k_prepare_bounded(const double* __restrict__ q, uint64_t Q, cons
   float x = (float)q[3 * i], y = (float)q[3 * i + 1], z = (float)q[3 * i + 2];
   bool ok = isfinite(x) && isfinite(y) && isfinite(z);
   qf4[i] = make_float4(x, y, z, ok ? 1.f : 0.f);
-  const double R = max_range ? max_range[mr_count == 1 ? 0 : i] : fixed_range;
-  uint64_t k = kKeyInit;
-  if (R == R) {   // not NaN
-    const double b = R < 0.0 ? 0.0 : R * R * (1.0 + 1e-5);
-    float bf = (float)b;
-    if ((double)bf < b) bf = nextafterf(bf, INFINITY);
-    if (bf < FLT_MAX) k = ((uint64_t)__float_as_uint(bf) << 32) | 0xFFFFFFFFull;
-  }
-  keys[i] = k;
+  keys[i] = bounded_init_key(max_range ? max_range[mr_count == 1 ? 0 : i] : fixed_range);
 }
 
-// keys still at their initial value (kKeyInit, or a bound with the impossible index) mean "nothing found"
 __global__ void k_finalize_keys(uint64_t* __restrict__ keys, uint64_t Q) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= Q) return;
   const uint64_t k = keys[i];
-  if (k == kKeyInit || (uint32_t)k == 0xFFFFFFFFu) keys[i] = PCD_KEY_NONE;
+  if (finalized_key(k) != k) keys[i] = PCD_KEY_NONE;
 }
 
 __global__ void k_unpack_keys(const uint64_t* __restrict__ keys, uint64_t Q, uint32_t* __restrict__ idx,
@@ -420,6 +425,13 @@ __global__ __launch_bounds__(1024) void k_fb_compact(const uint32_t* __restrict_
 }
 
 // --------------------------------------------------------- exact fallback ---
+struct FbFused {   // k_nn_fallback as the only launch of a call: 0 = off (queries from qf4, keys in and out raw)
+  int mode;        // 1 = plain query batch, 2 = gate-bounded
+  const double* q;
+  const double* max_range;
+  uint64_t mr_count;
+  double fixed_range;
+};
 #ifndef PCD_FB_LOADS
 #define PCD_FB_LOADS 4
 #endif
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
                                                       const uint32_t* __restrict__ list,  // NULL: queries 0..count-1
                                                       const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
                                                       uint64_t* __restrict__ keys, NnCounters* __restrict__ ctr,
-                                                      int collect_stats) {
+                                                      int collect_stats, FbFused fu) {
   __shared__ float s_lb[4][kMaxPyrLevels][64];
   __shared__ unsigned long long s_mask[4][kMaxPyrLevels];
   __shared__ int s_node[4][kMaxPyrLevels][3];
@@ -462,10 +474,24 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
   unsigned long long st_pts = 0, st_q = 0;
   for (uint32_t e = blockIdx.x * 4 + wave; e < count; e += nwaves) {
     const uint32_t qi = list ? list[e] : e;
-    const float4 q = qf4[qi];
-    if (q.w == 0.f) continue;  // not finite: stays "not found"
-    const float qx = q.x, qy = q.y, qz = q.z;
-    uint64_t best = keys[qi];  // kKeyInit or the brick kernel's tentative result
+    float qx, qy, qz;
+    uint64_t best;
+    if (fu.mode == 0) {
+      const float4 q = qf4[qi];
+      if (q.w == 0.f) continue;  // not finite: stays "not found"
+      qx = q.x; qy = q.y; qz = q.z;
+      best = keys[qi];  // kKeyInit or the brick kernel's tentative result
+    } else {
+      // one-launch form (small batches): the query is converted here and the key leaves finalised -- no prepare
+      // kernel in front, no finalize kernel behind (lidar/ply.cc:92: feature_point = point_3d.cast<float>())
+      qx = (float)fu.q[3 * (size_t)qi]; qy = (float)fu.q[3 * (size_t)qi + 1]; qz = (float)fu.q[3 * (size_t)qi + 2];
+      if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) {
+        if (lane == 0) keys[qi] = PCD_KEY_NONE;
+        continue;
+      }
+      best = fu.mode == 2 ? bounded_init_key(fu.max_range ? fu.max_range[fu.mr_count == 1 ? 0 : qi] : fu.fixed_range)
+                          : kKeyInit;
+    }
     uint64_t lane_best = best;
     float best_d = __uint_as_float((uint32_t)(best >> 32));
     int lev = top;
@@ -562,7 +588,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
         expand = true;
       }
     }
-    if (lane == 0) keys[qi] = best;
+    if (lane == 0) keys[qi] = fu.mode ? finalized_key(best) : best;
     st_q += 1;
   }
   if (collect_stats && lane == 0) {
@@ -638,7 +664,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), g_fb_max_blocks);
     hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, g, c->pyr, c->sorted.p, c->cell_start.p,
                        c->blk_aabb.p, c->sub_aabb.p, sc->qf4.p, sc->fb_dense.p, &sc->counters.p->pad[0], 0u, d_keys,
-                       sc->counters.p, g_collect_stats);
+                       sc->counters.p, g_collect_stats, FbFused{0, nullptr, nullptr, 0, 0.0});
   }
   return PCD_OK;
 }
@@ -655,6 +681,23 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
   QueryScratch* sc = scratch_of(c);
   if (Q == 0) return PCD_OK;
   PCD_REQUIRE(Q < 0xFFFFFFF0ull, "more than 2^32 queries in one call");
+  // Small batches (and PCD_NN_FALLBACK_ONLY): ONE launch -- k_nn_fallback converts the queries itself and writes
+  // finalised keys, so the per-call latency is one kernel instead of prepare + memset + search + finalize.
+  const bool one_launch = c->m > 0 && !refine &&
+                          (algo == PCD_NN_FALLBACK_ONLY || (algo == PCD_NN_AUTO && Q <= kSmallBatch));
+  if (one_launch) {
+    PCD_TRY(sc->counters.reserve(1));
+    if (g_collect_stats) PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
+    ScopedKernelTimer t("nn_fallback", s);
+    const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), g_fb_max_blocks);
+    const FbFused fu{bound ? 2 : 1, d_q, bound ? bound->d_max_range : nullptr, bound ? bound->count : 0,
+                     bound ? bound->fixed : 0.0};
+    hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, c->grid, c->pyr, c->sorted.p, c->cell_start.p,
+                       c->blk_aabb.p, c->sub_aabb.p, (const float4*)nullptr, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, (uint32_t)Q, d_keys, sc->counters.p, g_collect_stats, fu);
+    PCD_HIP_TRY(hipGetLastError());
+    return PCD_OK;
+  }
   PCD_TRY(sc->qf4.reserve(Q));
   {
     ScopedKernelTimer t("nn_prepare", s);
@@ -679,13 +722,14 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
       hipLaunchKernelGGL(k_nn_bruteforce, dim3(qblocks, chunks), dim3(256), 0, s, c->pts4.p, c->n, c->index_base,
                          c->index_stride, sc->qf4.p, Q, chunk, d_keys);
     } else if (algo == PCD_NN_FALLBACK_ONLY || (algo == PCD_NN_AUTO && Q <= kSmallBatch)) {
+      // (refining another shard's keys: the keys come in, so the prepare / finalize kernels stay)
       PCD_TRY(sc->counters.reserve(1));
       PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
       ScopedKernelTimer t("nn_fallback", s);
       const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), g_fb_max_blocks);
       hipLaunchKernelGGL(k_nn_fallback, dim3(blocks), dim3(256), 0, s, c->grid, c->pyr, c->sorted.p, c->cell_start.p,
                          c->blk_aabb.p, c->sub_aabb.p, sc->qf4.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)Q,
-                         d_keys, sc->counters.p, g_collect_stats);
+                         d_keys, sc->counters.p, g_collect_stats, FbFused{0, nullptr, nullptr, 0, 0.0});
     } else if (algo == PCD_NN_AUTO || algo == PCD_NN_GRID) {
       PCD_TRY(run_grid<8>(c, sc, Q, d_keys, s, refine || bound != nullptr));   // incoming keys matter: carry them
     } else {
