@@ -113,12 +113,20 @@ __global__ void k_prepare_refine(const double* __restrict__ q, uint64_t Q, const
 // The search starts from key = (bound, index 0xFFFFFFFF) instead of (FLT_MAX, 0): every candidate at or inside the
 // bound beats it, everything beyond is pruned by the same exact float bounds as ever, and a key that still carries
 // the impossible index at the end means "nothing within the gate" (-> PCD_KEY_NONE, type 0, as the reference's gate
-// decides).  bound = float >= R^2 (1 + 1e-5): the float distance of any point that passes the double-precision gate
+// decides).  bound = float >= (R + e)^2 (1 + 1e-5), e = the query's float rounding (bounded_init_key): the float distance of any point that passes the double-precision gate
 // is below it.  NaN range: the reference's `dist > range` is false, nothing is rejected -> unbounded.
-__device__ __forceinline__ uint64_t bounded_init_key(double R) {
+// (x, y, z): the query in double.  The gate compares R with the DOUBLE distance |double(p_float) - q_double|
+// (lidar_point.cc:27-30), the search minimises the FLOAT distance |p_float - float(q)|: the two differ by up to
+// |q_double - float(q)| <= 0.5 ulp per axis -- millimetres for coordinates of kilometres -- plus the rounding of the
+// float arithmetic (relative 2e-7, inside the 1e-5 factor).  e = (|x| + |y| + |z|) 2^-23 bounds the first term twice
+// over, so every point the gate accepts has a float distance below (R + e)^2 (1 + 1e-5).  (Found by tools/nn_fuzz.py:
+// a cloud 8 km from the origin, 11 of 150 000 associations with double distance 0.3899 < R = 0.39 < float distance.)
+__device__ __forceinline__ uint64_t bounded_init_key(double R, double x, double y, double z) {
   uint64_t k = kKeyInit;
   if (R == R) {   // not NaN
-    const double b = R < 0.0 ? 0.0 : R * R * (1.0 + 1e-5);
+    const double e = (fabs(x) + fabs(y) + fabs(z)) * (1.0 / 8388608.0);
+    const double Rb = (R < 0.0 ? 0.0 : R) + e;
+    const double b = Rb * Rb * (1.0 + 1e-5);
     float bf = (float)b;
     if ((double)bf < b) bf = nextafterf(bf, INFINITY);
     if (bf < FLT_MAX) k = ((uint64_t)__float_as_uint(bf) << 32) | 0xFFFFFFFFull;
@@ -137,7 +145,7 @@ __global__ void k_prepare_bounded(const double* __restrict__ q, uint64_t Q, cons
   float x = (float)q[3 * i], y = (float)q[3 * i + 1], z = (float)q[3 * i + 2];
   bool ok = isfinite(x) && isfinite(y) && isfinite(z);
   qf4[i] = make_float4(x, y, z, ok ? 1.f : 0.f);
-  keys[i] = bounded_init_key(max_range ? max_range[mr_count == 1 ? 0 : i] : fixed_range);
+  keys[i] = bounded_init_key(max_range ? max_range[mr_count == 1 ? 0 : i] : fixed_range, q[3 * i], q[3 * i + 1], q[3 * i + 2]);
 }
 
 __global__ void k_finalize_keys(uint64_t* __restrict__ keys, uint64_t Q) {
@@ -489,7 +497,8 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
         if (lane == 0) keys[qi] = PCD_KEY_NONE;
         continue;
       }
-      best = fu.mode == 2 ? bounded_init_key(fu.max_range ? fu.max_range[fu.mr_count == 1 ? 0 : qi] : fu.fixed_range)
+      best = fu.mode == 2 ? bounded_init_key(fu.max_range ? fu.max_range[fu.mr_count == 1 ? 0 : qi] : fu.fixed_range,
+                                             fu.q[3 * (size_t)qi], fu.q[3 * (size_t)qi + 1], fu.q[3 * (size_t)qi + 2])
                           : kKeyInit;
     }
     uint64_t lane_best = best;

@@ -208,3 +208,29 @@ def test_gate_bounded_search(gpu, oracle, mode):
             assert bnd["type"][100:110].any() or not typ[100:110].any()
             assert not bnd["type"][110:120].any()
     c.close()
+
+
+@pytest.mark.parametrize("Q", [20000, 90000], ids=["one-launch path", "grid path"])
+def test_gate_bounded_search_far_from_origin(gpu, Q):
+    """A cloud 8 km from the origin: float(query) is off by up to half a millimetre per axis there, so the float
+    distance the search minimises and the double distance the gate tests differ by ~1e-3 m -- more than any relative
+    slack on R^2.  The bound must widen by the query's float rounding (nn.hip bounded_init_key), or associations whose
+    double distance is just inside the gate get lost (found by tools/nn_fuzz.py: 11 of 150 000).  Ranges are drawn so
+    that many queries sit within a millimetre of their gate."""
+    rng = np.random.default_rng(19)
+    xyz = (rng.random((3000, 3)) * np.array([5.5, 20.0, 12.0]) + np.array([4629.5, 8267.2, 6565.5])).astype(np.float32)
+    nrm = np.zeros_like(xyz); nrm[:, 2] = 1.0
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    q = 0.5 * (xyz[rng.integers(0, 3000, Q)].astype(np.float64) + xyz[rng.integers(0, 3000, Q)].astype(np.float64))
+    free = c.associate(q, 1e9, 0)                                  # ungated distances
+    d = free["dist"]
+    mr = d + rng.uniform(-2e-3, 2e-3, Q)                           # gates within +-2 mm of the true distance
+    mr[::3] = np.round(rng.uniform(0.1, 2.0, Q), 2)[::3]
+    a0 = c.associate(q, mr, 0)
+    a1 = c.associate(q, mr, gpu.GATE_BOUNDED_SEARCH)
+    assert np.array_equal(a0["type"], a1["type"]), np.nonzero(a0["type"] != a1["type"])[0][:10]
+    acc = a0["type"] != 0
+    assert 0.2 * Q < acc.sum() < 0.9 * Q
+    for k in ("lidar_xyz", "abcd", "dist", "angle"):
+        assert np.array_equal(a0[k][acc], a1[k][acc], equal_nan=True), k   # angle is 0/0 for a query on its point
+    c.close()
