@@ -41,7 +41,7 @@ def make_cloud(kind, n):
 
 while time.time() < t_end:
     kind = rng.choice(["uniform", "planes", "lattice", "duplicates", "line", "plane_axis"])
-    n = int(rng.choice([50, 3000, 40000, 300000]))
+    n = int(rng.choice([50, 3000, 40000, 300000, 2000000], p=[0.2, 0.25, 0.25, 0.25, 0.05]))
     xyz = make_cloud(kind, n)
     if rng.random() < 0.3:
         xyz = (xyz + rng.choice([1e3, -5e3, 1e4]) * rng.random(3)).astype(np.float32)
@@ -49,7 +49,8 @@ while time.time() < t_end:
     nrm = np.zeros_like(xyz); nrm[:, 2] = 1
     cell = float(rng.choice([0.0, 0.0, 0.1, 0.37, 1.3]))
     c = pcdhip.Cloud(xyz, nrm, raw_lidar_frame=False, cell_size=cell)
-    Q = int(rng.choice([1, 7, 500, 20000, 70000, 150000]))
+    Q = int(rng.choice([1, 7, 500, 20000, 70000, 150000, 300000, 700000], p=[0.1, 0.1, 0.15, 0.2, 0.15, 0.15, 0.1, 0.05]))
+    # (>= 262144 queries: rocPRIM's Onesweep in the bookkeeping, below: its merge sort)
     lo, hi = xyz.min(0).astype(np.float64), xyz.max(0).astype(np.float64)
     mode = rng.choice(["near", "uniform", "mid", "outside"])
     if mode == "near":
