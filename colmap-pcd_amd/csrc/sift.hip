@@ -37,6 +37,13 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int kSiftTile = 128;
 constexpr int kSiftPitch = 144;   // bytes per staged descriptor row (128 + 16 pad)
 constexpr int kSiftConst = 128 * 128 * 128;
+#ifndef PCD_SIFT_BBUFS
+#define PCD_SIFT_BBUFS 2
+#endif
+#ifndef PCD_SIFT_WGS
+#define PCD_SIFT_WGS 2
+#endif
+constexpr int kSiftBBufs = PCD_SIFT_BBUFS;   // LDS copies of the set-2 tile in the stripe kernel
 
 __global__ void k_sift_rowsum(const uint8_t* __restrict__ da, int na, int* __restrict__ suma,
                               const uint8_t* __restrict__ db, int nb, int* __restrict__ sumb) {
@@ -203,8 +210,8 @@ __device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int 
                                             int4* __restrict__ part12, int4* __restrict__ part21, int nbx,
                                             int ct_per_chunk, const int chunk, const int by) {
   __shared__ __attribute__((aligned(16))) uint8_t sA[kSiftTile * kSiftPitch];
-  __shared__ __attribute__((aligned(16))) uint8_t sB[2][kSiftTile * kSiftPitch];
-  __shared__ int sSumA[kSiftTile], sSumB[2][kSiftTile];
+  __shared__ __attribute__((aligned(16))) uint8_t sB[kSiftBBufs][kSiftTile * kSiftPitch];
+  __shared__ int sSumA[kSiftTile], sSumB[kSiftBBufs][kSiftTile];
   __shared__ int4 sMerge[2][64];   // [64-column half of the stripe][column]
   const int row0 = by * kSiftTile;
   const int bx0 = chunk * ct_per_chunk, bx1 = min(bx0 + ct_per_chunk, nbx);
@@ -253,41 +260,42 @@ __device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int 
   int rb[2] = {0, 0}, rs[2] = {0, 0}, ra[2] = {-1, -1};
 
   for (int bx = bx0; bx < bx1; ++bx) {
-    const int buf = (bx - bx0) & 1;
+    const int buf = kSiftBBufs == 2 ? ((bx - bx0) & 1) : 0;
     const int col0 = bx * kSiftTile;
     if (bx + 1 < bx1) fetch_b(bx + 1);   // lands while this tile is multiplied and scanned
 
-    // accumulators start at 128 * rowsum(row): the scans need no per-element add
-    v16i acc1[2][2], acc2[2][2];   // acc1[mt][nt]: rows = set-1, cols = set-2;  acc2[nt][mt]: rows = set-2, cols = set-1
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int rr = a * 32 + (k & 3) + 8 * (k >> 2) + 4 * lh;
-        const int va = 128 * sSumA[wr * 64 + rr], vb = 128 * sSumB[buf][wc * 64 + rr];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) { acc1[a][c][k] = va; acc2[a][c][k] = vb; }
-      }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      v4i fa[2], fb[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        fa[t] = *reinterpret_cast<const v4i*>(sA + (wr * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
-        fb[t] = *reinterpret_cast<const v4i*>(sB[buf] + (wc * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          acc1[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mt], fb[nt], acc1[mt][nt], 0, 0, 0);
-          acc2[nt][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[nt], fa[mt], acc2[nt][mt], 0, 0, 0);
-        }
-    }
-
-    // packed top-2 scans (see k_sift_scores): value = score << 8 | (255 - row in the 128-row tile)
+    // One orientation at a time over the same 64 accumulator registers: first A.B^T (rows = set 1: the scan gives the
+    // best set-1 row for every set-2 column), then B.A^T.  Computing both at once needed 128 accumulators and held
+    // the kernel at 2 wavefronts per SIMD.
 #pragma unroll
     for (int dir = 0; dir < 2; ++dir) {
+      v16i acc[2][2];   // dir 0: acc[mt][nt], rows = set 1;  dir 1: acc[nt][mt], rows = set 2
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int rr = a * 32 + (k & 3) + 8 * (k >> 2) + 4 * lh;
+          const int v0 = 128 * (dir == 0 ? sSumA[wr * 64 + rr] : sSumB[buf][wc * 64 + rr]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[a][c][k] = v0;
+        }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        v4i fa[2], fb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          fa[t] = *reinterpret_cast<const v4i*>(sA + (wr * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
+          fb[t] = *reinterpret_cast<const v4i*>(sB[buf] + (wc * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            if (dir == 0) acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+            else acc[nt][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+          }
+      }
+      // packed top-2 scan (see k_sift_scores): value = score << 8 | (255 - row in the 128-row tile)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const int ccol = (dir == 0 ? wc : wr) * 64 + ct * 32 + lr;
@@ -298,11 +306,11 @@ __device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int 
         int best = init, second = init;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-          const v16i& acc = dir == 0 ? acc1[rt][ct] : acc2[rt][ct];
+          const v16i& av = acc[rt][ct];
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg) {
             const unsigned code = code_base - (unsigned)(rt * 32 + (reg & 3) + 8 * (reg >> 2));
-            const int v = (int)(((unsigned)acc[reg] << 8) | code);
+            const int v = (int)(((unsigned)av[reg] << 8) | code);
             int med;
             asm("v_med3_i32 %0, %1, %2, %3" : "=v"(med) : "v"(best), "v"(second), "v"(v));
             second = med;
@@ -325,8 +333,14 @@ __device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int 
         }
       }
     }
-    if (bx + 1 < bx1) store_b(buf ^ 1);
-    __syncthreads();
+    if (kSiftBBufs == 2) {
+      if (bx + 1 < bx1) store_b(buf ^ 1);
+      __syncthreads();
+    } else {
+      __syncthreads();                       // every wavefront is done with the tile
+      if (bx + 1 < bx1) store_b(0);
+      __syncthreads();
+    }
   }
 
   // the two waves that share stripe rows (wc = 0, 1: the two 64-row halves of every column tile) merge
@@ -345,7 +359,7 @@ __device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int 
   }
 }
 
-__global__ __launch_bounds__(256, 2) void k_sift_scores_stripe(const uint8_t* __restrict__ d1, int n1,
+__global__ __launch_bounds__(256, PCD_SIFT_WGS) void k_sift_scores_stripe(const uint8_t* __restrict__ d1, int n1,
                                                             const uint8_t* __restrict__ d2, int n2,
                                                             const int* __restrict__ sum1, const int* __restrict__ sum2,
                                                             int4* __restrict__ part12, int4* __restrict__ part21,
@@ -363,7 +377,7 @@ struct SiftPairDev {
   uint64_t match;                // offset (in matches) of the pair's output list
 };
 
-__global__ __launch_bounds__(256, 2) void k_sift_scores_batch(const uint8_t* __restrict__ arena,
+__global__ __launch_bounds__(256, PCD_SIFT_WGS) void k_sift_scores_batch(const uint8_t* __restrict__ arena,
                                                            const int* __restrict__ sum,
                                                            const SiftPairDev* __restrict__ pairs,
                                                            int4* __restrict__ part12, int4* __restrict__ part21,
