@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
   const int collect_stats = flags & 1;
   static_assert(G == 8, "the transposed reduction is written for 8 queries per group");
   __shared__ __attribute__((aligned(16))) float4 s_tile[4][2][kTile];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform for the compiler too: LDS tile addresses and M0 values stay in SGPRs
   const uint32_t nitems = ctr->nitems;
   const uint32_t nwaves = gridDim.x * 4;
   unsigned long long st_staged = 0, st_pairs = 0, st_groups = 0;
