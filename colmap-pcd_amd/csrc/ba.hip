@@ -277,7 +277,8 @@ template <int MODEL, bool WANT_W>
 __global__ __launch_bounds__(256) void k_ba_images(BaDev d, double* __restrict__ partial, double* __restrict__ W_o) {
   __shared__ __attribute__((aligned(16))) double s_w[WANT_W ? 4 : 1][WANT_W ? 64 * 18 : 2];
   const int im = (int)d.seg_img[blockIdx.x];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform for the compiler
   const bool cpose = d.image_const_pose && d.image_const_pose[im];
   double acc[27];
 #pragma unroll

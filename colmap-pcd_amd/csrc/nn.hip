@@ -477,7 +477,8 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
   __shared__ float s_lb[4][kMaxPyrLevels][64];
   __shared__ unsigned long long s_mask[4][kMaxPyrLevels];
   __shared__ int s_node[4][kMaxPyrLevels][3];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform for the compiler: LDS addresses on the scalar unit
   const uint32_t count = count_ptr ? *count_ptr : count_imm;
   const uint32_t nwaves = gridDim.x * 4;
   const int top = py.nlev - 1;  // >= 1

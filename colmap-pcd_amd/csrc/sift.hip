@@ -215,7 +215,8 @@ __device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int 
   __shared__ int4 sMerge[2][64];   // [64-column half of the stripe][column]
   const int row0 = by * kSiftTile;
   const int bx0 = chunk * ct_per_chunk, bx1 = min(bx0 + ct_per_chunk, nbx);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform for the compiler: tile coordinates and LDS bases on the scalar unit
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
   if (bx0 >= bx1) return;
