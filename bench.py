@@ -35,23 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "colmap-pcd_amd"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import pcdhip  # noqa: E402
-from pcdhip import dist as pdist  # noqa: E402
-from pcdhip import synth  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-POINT_BYTES = 12                 # xyz fp32 per staged cloud point
-REC_BYTES = 16                   # what the layout actually streams: {x,y,z,index} records
-PER_QUERY_BYTES = 20             # 12 B query in + 8 B key out
-
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks of the run (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cloud", type=int, default=10_000_000)
@@ -65,6 +52,57 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the raw-mode / e2e / config-A legs")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path)")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE this process has made any GPU
+    call (nothing GPU-related is even imported yet), as plain child processes -- one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment -- and relay rank 0's JSON line.  (A process that has touched the GPU
+    must never be replaced by exec on this pool; children are started with subprocess, this parent only waits.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        sys.exit(1)
+    sys.exit(0)
+
+
+ARGS = parse() if __name__ == "__main__" else None
+if ARGS is not None:
+    _ws = os.environ.get("WORLD_SIZE")
+    if ARGS.gpus is None:
+        ARGS.gpus = int(_ws) if _ws else 1
+    if _ws is None and ARGS.gpus > 1:
+        launch_ranks(ARGS)          # does not return
+    if _ws is not None and int(_ws) != ARGS.gpus:
+        sys.stderr.write(f"bench.py: --gpus {ARGS.gpus} but the launcher set WORLD_SIZE={_ws}\n")
+        sys.exit(2)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import pcdhip  # noqa: E402
+from pcdhip import dist as pdist  # noqa: E402
+from pcdhip import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+POINT_BYTES = 12                 # SURVEY 8d: xyz fp32 per staged cloud point
+REC_BYTES = 16                   # what the layout actually streams: {x,y,z,index} records
+PER_QUERY_BYTES = 20             # 12 B query in + 8 B key out
 
 
 def source_hash():
@@ -146,7 +184,7 @@ def timed(fn, steps, sync):
 
 
 def main():
-    a = parse()
+    a = ARGS
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,6 +200,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream().cuda_stream
+    # what the collective layer itself saw: ranks, backend, and the physical device behind every rank
+    pr = torch.cuda.get_device_properties(local_rank)
+    my_dev = dict(rank=rank, index=local_rank, name=pr.name,
+                  id=str(getattr(pr, "uuid", None) or getattr(pr, "pci_bus_id", None) or local_rank))
+    dist_info = dict(world_size=1, backend=None, devices=[my_dev], distinct_devices=1)
+    if world > 1:
+        devs = [None] * world
+        dist.all_gather_object(devs, my_dev)
+        dist_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), devices=devs,
+                         distinct_devices=len({d["id"] for d in devs}))
+        assert dist_info["world_size"] == a.gpus, (dist_info, a.gpus)
+        if a.backend == "nccl" and os.environ.get("PCD_BENCH_FORCE_DEVICE") is None:
+            assert dist_info["distinct_devices"] == world, f"{world} ranks on {dist_info['distinct_devices']} devices: {devs}"
 
     # ------------------------------------------------------------ inputs (seeded) ---
     # ONE workload for every N: the same cloud, queries and scene on every rank; rank r works on its share.
@@ -276,6 +327,23 @@ def main():
         t_nn = timed(nn_step, a.steps, sync)
         t_ba = timed(ba_step, a.steps, sync)
         extras.update(ba_raw_iter_ms=t_raw * 1e3, nn_wall_ms=t_nn * 1e3, ba_wall_ms=t_ba * 1e3, ba_create_ms=ba_create_ms)
+        if world == 1:
+            # N > 1 runs cut the queries in a spatially compact order (done on the host, outside the timed region):
+            # the like-for-like single-GPU figure for a scaling ratio is this one, on the SAME pre-sorted queries
+            perm = pdist.compact_order(q_all)
+            dq_c = torch.from_numpy(np.ascontiguousarray(q_all[perm])).to(dev)
+            dmr_c = torch.from_numpy(np.ascontiguousarray(mr_all[perm])).to(dev)
+
+            def nn_step_c():
+                cloud.nn_device(dq_c, Q, keys, pcdhip.NN_AUTO, stream)
+                cloud.associate_device(dq_c, Q, dmr_c, Q, pcdhip.GATE_MAPPER_LOCAL, aout, keys, stream)
+            for _ in range(2):
+                nn_step_c()
+            extras["nn_wall_ms_compact_order"] = timed(nn_step_c, a.steps, sync) * 1e3
+            extras["scaling_note"] = ("N > 1 legs pre-sort the queries spatially on the host (untimed, once per query "
+                                      "set); compare them with nn_wall_ms_compact_order + ba_wall_ms, not with "
+                                      "ms_per_step, for a like-for-like strong-scaling ratio")
+            del dq_c, dmr_c
         del raw, res_only
         # ---- what the call sites need: the search bounded by each query's gate (PCD_GATE_BOUNDED_SEARCH) --------
         # same recorded associations, same field values (tests/test_assoc_gpu.py::test_gate_bounded_search); the
@@ -362,7 +430,7 @@ def main():
             "metric": "NN queries/sec + BA-iter ms, 10M-pt cloud / 1M 3D feats",
             "value": Qtot / (dt / a.steps),
             "unit": "queries/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "dist": dist_info, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 (NN distances) / f64 (association, BA)", "data": "synthetic",
             "config": {"workload": f"M: {a.cloud}-pt 'planes' cloud / {Qtot} queries + BA scene "

@@ -287,6 +287,7 @@ pcd_status pcd_assoc_staging(pcd_cloud* c, uint64_t Q, double** q_xyz, double** 
 pcd_status pcd_associate_staged(pcd_cloud* c, uint64_t Q, uint64_t max_range_count, int gate_mode,
                                 const pcd_assoc_hit** hits, uint64_t* num_hits) {
   PCD_REQUIRE(c && hits && num_hits, "null pointer");
+  gate_mode &= ~PCD_GATE_BOUNDED_SEARCH;   // always searched gate-bounded here; the flag is accepted like everywhere else
   PCD_REQUIRE(gate_mode >= 0 && gate_mode <= 2, "gate_mode");
   PCD_REQUIRE(gate_mode == PCD_GATE_CONTROLLER || max_range_count == 1 || max_range_count == Q,
               "max_range must have 1 or Q entries");

@@ -836,6 +836,14 @@ static void build_csr(const int32_t* key, uint64_t n, int nkeys, std::vector<uin
     default: { constexpr int M = -1; __VA_ARGS__; } break;        \
   }
 
+// Grid of the kernel that writes cost_partial[blockIdx.x]: k_ba_points takes two 64-track slices per workgroup,
+// k_ba_cost sweeps the residual blocks with a capped grid.  pcd_ba_create sizes cost_partial from the SAME function
+// (round 2 sized it for an older k_ba_points grid: scenes with O + L < ~2 P wrote past the end).
+static unsigned cost_blocks(const pcd_ba* b, bool want_blocks) {
+  return want_blocks ? std::max(1u, div_up((size_t)b->nslices, 2))
+                     : std::max(1u, std::min(kCostBlocks, div_up(b->O + b->L, 256)));
+}
+
 extern "C" {
 
 pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
@@ -964,7 +972,8 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
     }
   }
 #undef UP
-  pcd_status s1 = b->cost_partial.reserve(std::max<size_t>(div_up((size_t)b->nslices * 64, 256), div_up(b->O + b->L, 256)) + 1);
+  // one partial per workgroup of whichever of the two cost-producing kernels has the larger grid (cost_blocks)
+  pcd_status s1 = b->cost_partial.reserve((size_t)std::max(cost_blocks(b, true), cost_blocks(b, false)) + 1);
   if (s1 != PCD_OK) return fail(s1);
   if ((s1 = b->cost.reserve(1)) != PCD_OK) return fail(s1);
   *out = b;
@@ -1007,8 +1016,7 @@ pcd_status pcd_ba_evaluate_device(pcd_ba* b, const pcd_ba_out* o, void* stream) 
   const int model = b->uniform_model;
   if (o->cost || o->H_pt || o->g_pt) {
     const bool want_blocks = o->H_pt || o->g_pt;
-    const unsigned blocks = want_blocks ? div_up((size_t)b->nslices, 2)
-                                        : std::max(1u, std::min(kCostBlocks, div_up(b->O + b->L, 256)));
+    const unsigned blocks = cost_blocks(b, want_blocks);
     {
       ScopedKernelTimer t(want_blocks ? "ba_points" : "ba_points_cost", s);
       if (want_blocks) {

@@ -553,10 +553,41 @@ struct SiftScratch {
   DevBuf<int> counts;
   DevBuf<uint64_t> dense_off;
   DevBuf<uint32_t> dense;
+  // The scratch is per DEVICE and shared by every call on it.  Host side: g_sift_mu (recursive) is held for the whole
+  // of a host entry point and while a *_device entry point enqueues.  Device side: calls on different streams are
+  // ordered through ev_done (the next call's stream waits for the previous call's last kernel before any of its own
+  // work touches part12 / m12 / pairs ...; calls on one stream are ordered anyway).  The pair table goes up with an
+  // asynchronous copy on the caller's stream from h_pairs; ev_tab guards the pinned buffer against being rewritten
+  // while that copy is still in flight.
+  PinnedBuf<SiftPairDev> h_pairs;
+  hipEvent_t ev_done = nullptr, ev_tab = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool used = false, tab_pending = false;
+  ~SiftScratch() {
+    if (ev_done) (void)hipEventDestroy(ev_done);
+    if (ev_tab) (void)hipEventDestroy(ev_tab);
+  }
 };
 static SiftScratch* g_sift[64] = {nullptr};
 static int g_sift_tile_kernel = 0;   // 1 = one 128x128 tile per workgroup (the first design; A/B timing via PCD_SIFT_TILE=1)
-static std::mutex g_sift_mu;
+static std::recursive_mutex g_sift_mu;
+typedef std::lock_guard<std::recursive_mutex> SiftLock;
+
+// bracket of every use of the shared scratch on stream s (g_sift_mu held)
+static pcd_status sift_begin_use(SiftScratch& sc, hipStream_t s) {
+  if (!sc.ev_done) {
+    PCD_HIP_TRY(hipEventCreateWithFlags(&sc.ev_done, hipEventDisableTiming));
+    PCD_HIP_TRY(hipEventCreateWithFlags(&sc.ev_tab, hipEventDisableTiming));
+  }
+  if (sc.used && sc.last_stream != s) PCD_HIP_TRY(hipStreamWaitEvent(s, sc.ev_done, 0));
+  return PCD_OK;
+}
+static pcd_status sift_end_use(SiftScratch& sc, hipStream_t s) {
+  PCD_HIP_TRY(hipEventRecord(sc.ev_done, s));
+  sc.last_stream = s;
+  sc.used = true;
+  return PCD_OK;
+}
 
 static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uint8_t* d_d2, int n2, float max_ratio,
                               float max_distance, int cross_check, int* d_m12, int* d_m21, uint32_t* d_matches,
@@ -690,8 +721,14 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
   PCD_TRY(sc.pairs.reserve(n_pairs));
   PCD_TRY(sc.part12.reserve(max12)); PCD_TRY(sc.part21.reserve(max21));
   PCD_TRY(sc.m12.reserve(maxm12)); PCD_TRY(sc.m21.reserve(maxm21));
-  // blocking copy from pageable memory: complete when it returns, so `tab` may go out of scope
-  PCD_HIP_TRY(hipMemcpy(sc.pairs.p, tab.data(), sizeof(SiftPairDev) * (size_t)n_pairs, hipMemcpyHostToDevice));
+  // the table goes up ON THE CALLER'S STREAM (a null-stream copy is not ordered against a non-blocking stream: a second
+  // call could overwrite sc.pairs under the first call's kernels); pinned staging, guarded by ev_tab
+  if (sc.tab_pending) PCD_HIP_TRY(hipEventSynchronize(sc.ev_tab));
+  PCD_TRY(sc.h_pairs.reserve(n_pairs));
+  std::memcpy(sc.h_pairs.p, tab.data(), sizeof(SiftPairDev) * (size_t)n_pairs);
+  PCD_HIP_TRY(hipMemcpyAsync(sc.pairs.p, sc.h_pairs.p, sizeof(SiftPairDev) * (size_t)n_pairs, hipMemcpyHostToDevice, s));
+  PCD_HIP_TRY(hipEventRecord(sc.ev_tab, s));
+  sc.tab_pending = true;
   for (size_t k = 0; k + 1 < cut.size(); ++k) {
     const int p0 = cut[k], np = cut[k + 1] - cut[k], nchunk = cut_nchunk[k];
     uint32_t mx1 = 0, mx2 = 0, mxsum = 0;
@@ -739,10 +776,14 @@ pcd_status pcd_sift_match_device(int device, const uint8_t* d_desc1, int n1, con
   }
   PCD_REQUIRE(d_desc1 && d_desc2 && d_m12 && d_m21 && d_matches, "null pointer");
   PCD_REQUIRE(device < 64, "device ordinal");
-  std::lock_guard<std::mutex> g(g_sift_mu);
+  SiftLock g(g_sift_mu);
+  PCD_HIP_TRY(hipSetDevice(device));
   if (!g_sift[device]) g_sift[device] = new SiftScratch();
-  return sift_device(device, d_desc1, n1, d_desc2, n2, max_ratio, max_distance, cross_check, d_m12, d_m21, d_matches,
-                     d_num_matches, *g_sift[device], s);
+  PCD_TRY(sift_begin_use(*g_sift[device], s));
+  const pcd_status st = sift_device(device, d_desc1, n1, d_desc2, n2, max_ratio, max_distance, cross_check, d_m12, d_m21,
+                                    d_matches, d_num_matches, *g_sift[device], s);
+  PCD_TRY(sift_end_use(*g_sift[device], s));
+  return st;
 }
 
 pcd_status pcd_sift_match(int device, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float max_ratio,
@@ -753,16 +794,15 @@ pcd_status pcd_sift_match(int device, const uint8_t* desc1, int n1, const uint8_
   PCD_REQUIRE(desc1 && desc2 && matches, "null pointer");
   PCD_REQUIRE(device >= 0 && device < 64, "device ordinal");
   PCD_TRY(require_device(device));
-  SiftScratch* sc;
-  {
-    std::lock_guard<std::mutex> g(g_sift_mu);
-    if (!g_sift[device]) g_sift[device] = new SiftScratch();
-    sc = g_sift[device];
-  }
+  SiftLock g(g_sift_mu);   // the whole host call: it owns the scratch's d1 / d2 / m12 / matches until it has synchronised
+  PCD_HIP_TRY(hipSetDevice(device));
+  if (!g_sift[device]) g_sift[device] = new SiftScratch();
+  SiftScratch* sc = g_sift[device];
+  hipStream_t s = nullptr;
+  PCD_TRY(sift_begin_use(*sc, s));   // an earlier *_device call on another stream may still be reading the scratch
   PCD_TRY(sc->d1.reserve((size_t)n1 * 128)); PCD_TRY(sc->d2.reserve((size_t)n2 * 128));
   PCD_TRY(sc->m12.reserve(n1)); PCD_TRY(sc->m21.reserve(n2)); PCD_TRY(sc->matches.reserve(2 * (size_t)n1));
   PCD_TRY(sc->count.reserve(1));
-  hipStream_t s = nullptr;
   PCD_HIP_TRY(hipMemcpyAsync(sc->d1.p, desc1, (size_t)n1 * 128, hipMemcpyHostToDevice, s));
   PCD_HIP_TRY(hipMemcpyAsync(sc->d2.p, desc2, (size_t)n2 * 128, hipMemcpyHostToDevice, s));
   PCD_TRY(pcd_sift_match_device(device, sc->d1.p, n1, sc->d2.p, n2, max_ratio, max_distance, cross_check, sc->m12.p,
@@ -786,10 +826,15 @@ pcd_status pcd_sift_match_batch_device(int device, const uint8_t* d_arena, const
   PCD_REQUIRE(first_row[n_images] == 0 || d_arena, "null arena");
   PCD_REQUIRE(device >= 0 && device < 64, "device ordinal");
   PCD_TRY(require_device(device));
-  std::lock_guard<std::mutex> g(g_sift_mu);
+  SiftLock g(g_sift_mu);
+  PCD_HIP_TRY(hipSetDevice(device));
   if (!g_sift[device]) g_sift[device] = new SiftScratch();
-  return sift_batch_device(device, d_arena, first_row, n_images, pairs, n_pairs, max_ratio, max_distance, cross_check,
-                           d_matches, match_offset, d_counts, *g_sift[device], (hipStream_t)stream);
+  PCD_TRY(sift_begin_use(*g_sift[device], (hipStream_t)stream));
+  const pcd_status st = sift_batch_device(device, d_arena, first_row, n_images, pairs, n_pairs, max_ratio, max_distance,
+                                          cross_check, d_matches, match_offset, d_counts, *g_sift[device],
+                                          (hipStream_t)stream);
+  PCD_TRY(sift_end_use(*g_sift[device], (hipStream_t)stream));
+  return st;
 }
 
 pcd_status pcd_sift_match_batch(int device, const uint8_t* arena, const uint64_t* first_row, int n_images,
@@ -803,12 +848,11 @@ pcd_status pcd_sift_match_batch(int device, const uint8_t* arena, const uint64_t
   PCD_TRY(require_device(device));
   const uint64_t rows = first_row[n_images];
   PCD_REQUIRE(rows == 0 || arena, "null arena");
-  SiftScratch* sc;
-  {
-    std::lock_guard<std::mutex> g(g_sift_mu);
-    if (!g_sift[device]) g_sift[device] = new SiftScratch();
-    sc = g_sift[device];
-  }
+  SiftLock g(g_sift_mu);   // the whole host call: arena / matches / counts / dense are the device's shared scratch
+  PCD_HIP_TRY(hipSetDevice(device));
+  if (!g_sift[device]) g_sift[device] = new SiftScratch();
+  SiftScratch* sc = g_sift[device];
+  PCD_TRY(sift_begin_use(*sc, nullptr));
   // worst-case list of pair p: one match per descriptor of its first image
   std::vector<uint64_t> off((size_t)n_pairs + 1, 0);
   for (int p = 0; p < n_pairs; ++p) {

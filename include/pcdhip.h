@@ -151,8 +151,10 @@ typedef enum { PCD_LIDAR_NONE = 0, PCD_LIDAR_ICP = 1, PCD_LIDAR_ICP_GROUND = 2 }
  * point-to-point distance exceeds max_range (mapper) / 2 m (controller), so no neighbour beyond that distance can be
  * recorded; with this flag the search prunes there (exact inside the bound), the set of recorded associations and
  * every field of their rows are identical, and rows with type 0 carry zeros / 0xFFFFFFFF instead of the rejected
- * winner.  Ignored when keys are passed in.  pcd_associate_staged always searches this way (it returns only the
- * recorded associations); pcd_nn_query* is never bounded. */
+ * winner: in bounded mode nn_idx / nn_sqdist are DEFINED ONLY FOR ACCEPTED ASSOCIATIONS (type != 0) -- a query whose
+ * gate rejects it reports 0xFFFFFFFF / FLT_MAX, not its true nearest neighbour.  Ignored when keys are passed in.
+ * pcd_associate_staged always searches this way (it returns only the recorded associations; the flag is accepted
+ * and redundant there); pcd_nn_query* is never bounded. */
 #define PCD_GATE_BOUNDED_SEARCH 0x100
 
 typedef struct {

@@ -249,3 +249,31 @@ def test_config_size_properties(gpu, oracle, cams, points, shard):
     _close(out["jac_X"][keep], oJX, 1e-9, "JX vs oracle")
     _close(res[2 * O:][lk], ores[2 * int(keep.sum()):], 1e-9, "lidar residuals vs oracle")
     ba.close()
+
+
+def test_sparse_scenes_cost_partials(gpu, oracle):
+    """Scenes with far fewer residual blocks than points (local BA with one observation per point; lidar-only):
+    k_ba_points runs one workgroup per two 64-track slices whatever O + L is, and each workgroup writes one cost
+    partial -- round 2 sized that buffer from O + L and wrote past its end.  The cost must equal the
+    oracle's and the bytes behind the partials (the next allocation, the handle's cost scalar buffer) must survive."""
+    P = 100_000
+    rng = np.random.default_rng(77)
+    s = synth.ba_scene(6, P, seed=78)
+    # (a) one observation per point: keep the first observation of every track
+    first = np.unique(s["obs_point"], return_index=True)[1]
+    a = dict(s)
+    a["obs_image"], a["obs_point"], a["obs_xy"] = s["obs_image"][first], s["obs_point"][first], s["obs_xy"][first]
+    keep = rng.random(len(s["lidar_point"])) < 0.02
+    a["lidar_point"], a["lidar_abcd"], a["lidar_weight"] = s["lidar_point"][keep], s["lidar_abcd"][keep], s["lidar_weight"][keep]
+    assert len(a["obs_image"]) + keep.sum() < 2 * P
+    # (b) no observations at all, a few lidar terms
+    b = dict(a)
+    b["obs_image"], b["obs_point"], b["obs_xy"] = a["obs_image"][:0], a["obs_point"][:0], a["obs_xy"][:0]
+    for sc in (a, b):
+        cost = oracle.BA(**sc).normal_equations()[0]
+        ba = gpu.BA(**sc)
+        for _ in range(2):
+            got = ba.evaluate(("cost", "H_pt", "g_pt"))
+            assert abs(got["cost"][0] - cost) <= 1e-11 * max(abs(cost), 1e-300)
+            assert abs(ba.evaluate(("cost",))["cost"][0] - cost) <= 1e-11 * max(abs(cost), 1e-300)
+        ba.close()
