@@ -3,6 +3,7 @@ include/pcdhip.h declares, and fails loudly (no CPU fallback) when there is no G
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -63,3 +64,11 @@ def test_product_does_not_import_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b|pyoracle|liboracle|#include\s*[<\"][^>\"]*oracle", txt, re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_bench_refuses_world_size_mismatch():
+    """bench.py --gpus N under a launcher that set another WORLD_SIZE must fail before touching anything"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True)
+    assert r.returncode == 2 and b"WORLD_SIZE=3" in r.stderr
