@@ -19,6 +19,7 @@
 
 namespace pcd {
 
+constexpr int kSortedSpare = 16;  // records behind the last point of `sorted` (copies of it): range reads may overrun
 constexpr int kBlockCells = 4;  // cells per block edge (blocks carry tight AABBs for the exact fallback)
 
 struct GridParams {

@@ -127,9 +127,10 @@ __global__ void k_cell_keys(const float4* __restrict__ pts4, uint64_t n, GridPar
 __global__ void k_gather_sorted(const float4* __restrict__ pts4, const uint32_t* __restrict__ order, uint64_t m,
                                 uint32_t index_base, uint32_t index_stride, float4* __restrict__ sorted) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-  if (i >= m + 4) return;
-  // rows m .. m+3 repeat the last record: the brick kernel reads ranges in groups of 4 records and may run up to
-  // 3 records past the end of the last range (brick_kernel.h); a repeated real point cannot change a minimum
+  if (i >= m + kSortedSpare) return;
+  // rows m .. m+15 repeat the last record: the brick kernel reads ranges in groups of 4 records and may run up to
+  // 3 records past the end of the last range (brick_kernel.h), the stencil kernel in steps of 16 records
+  // (stencil_kernel.h); a repeated real point cannot change a minimum
   uint32_t src = order[i < m ? i : m - 1];
   float4 p = pts4[src];
   p.w = __uint_as_float(index_base + src * index_stride);
@@ -355,7 +356,7 @@ static pcd_status build_grid(pcd_cloud* c, float user_h, hipStream_t s) {
   c->occupied = hc[0];
 
   // --- sort rows by cell (stable radix sort keeps original order inside a cell) ---
-  PCD_TRY(c->sorted.reserve(c->m + 4));   // + 4 spare records, see k_gather_sorted
+  PCD_TRY(c->sorted.reserve(c->m + kSortedSpare));   // spare records, see k_gather_sorted
   if (n) {
     DevBuf<uint32_t> k0, k1, v0, v1;
     PCD_TRY(k0.reserve(n)); PCD_TRY(k1.reserve(n)); PCD_TRY(v0.reserve(n)); PCD_TRY(v1.reserve(n));
@@ -366,7 +367,7 @@ static pcd_status build_grid(pcd_cloud* c, float user_h, hipStream_t s) {
     PCD_TRY(tmp.reserve(tb));
     PCD_HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, k0.p, k1.p, v0.p, v1.p, n, 0, 32, s));
     if (c->m)
-      hipLaunchKernelGGL(k_gather_sorted, dim3(div_up(c->m + 4, 256)), dim3(256), 0, s, c->pts4.p, v1.p, c->m,
+      hipLaunchKernelGGL(k_gather_sorted, dim3(div_up(c->m + kSortedSpare, 256)), dim3(256), 0, s, c->pts4.p, v1.p, c->m,
                          c->index_base, c->index_stride, c->sorted.p);
     PCD_HIP_TRY(hipStreamSynchronize(s));
   }

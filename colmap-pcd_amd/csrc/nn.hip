@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void k_brick_emit(const uint32_t* __restrict__
       q[k].w = __uint_as_float(v[k]);          // brick-sorted query record {x, y, z, bits(query id)}
       qsorted[j] = q[k];
       ksorted[j] = kin[k];
+      if (j + 1 == Q || keys[j + 1] >= nbricks) ctr->n_in_grid = j + 1;   // in-grid queries sort first
       if (flag[k]) {
         uint32_t cnt = 1;
         while (cnt < (uint32_t)G && j + cnt < Q && keys[j + cnt] == key[k]) ++cnt;
@@ -392,6 +393,7 @@ __device__ __forceinline__ double proven_bound(const GridParams& g, float qx, fl
 
 }  // namespace pcd
 #include "brick_kernel.h"
+#include "stencil_kernel.h"
 namespace pcd {
 
 
@@ -617,6 +619,57 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
 // workgroups: 0.384 / 0.387 / 0.368 / 0.369 ms at workload M, 0.136 / 0.125 / 0.126 / 0.125 ms on an eighth of it.
 constexpr unsigned g_fb_max_blocks = 16384;
 static int g_brick_B = 2, g_brick_R = 2, g_collect_stats = 0, g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
+// first stage of the grid path: 0 = brick kernel (brick_kernel.h), 1 = per-query stencil stages (stencil_kernel.h).
+// The stencil stages halve the point-query pairs (590 instead of 1 306 per query on workload M) but load every
+// point once PER QUERY instead of once per brick: 9.4 GB through the vector L1s per batch against the brick kernel's
+// 4.4 GB of LDS-DMA, and at 21 TB/s of L1 traffic they take 0.83 ms where the brick kernel takes 0.56
+// (profiles/r03_stencil_probe.txt).  Kept as a tested option (tests/test_nn_gpu.py::test_stencil_stage_cascades).
+static int g_nn_kernel = 0;
+static int g_st_k[3] = {1, 2, 0};            // cube half-widths of the stencil stages in cells (ascending; 0 = unused)
+constexpr unsigned kStencilBlocks = 256 * (16 / kStWaves);  // persistent grid: 16 wavefronts per CU (4 per SIMD) on 256 CUs
+
+template <int KPREV, int K>
+static void launch_stencil(pcd_cloud* c, QueryScratch* sc, const uint32_t* list, const uint32_t* count_ptr,
+                           uint64_t* d_keys, const StencilOut& out, hipStream_t s) {
+  hipLaunchKernelGGL((k_nn_stencil<KPREV, K>), dim3(kStencilBlocks), dim3(64 * kStWaves), 0, s, c->grid, c->sorted.p,
+                     c->cell_start.p, sc->qsorted.p, sc->ksorted.p, list, count_ptr, d_keys, out, sc->counters.p,
+                     g_collect_stats);
+}
+
+// The stencil stages over the brick-sorted queries (positions 0 .. n_in_grid-1); what the last stage cannot prove
+// lands on the fallback list.
+static pcd_status run_stencil_stages(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t* d_keys, hipStream_t s) {
+  int nst = 0;
+  while (nst < 3 && g_st_k[nst] > 0) ++nst;
+  const size_t cap = Q + Q / 8 + 64 + (size_t)kStencilBlocks * kStWaves * 64;
+  if (nst > 1) PCD_TRY(sc->st_list[0].reserve(cap));
+  if (nst > 2) PCD_TRY(sc->st_list[1].reserve(cap));
+  NnCounters* ctr = sc->counters.p;
+  int kprev = 0;
+  for (int i = 0; i < nst; ++i) {
+    const int k = g_st_k[i];
+    const bool last = i + 1 == nst;
+    const uint32_t* list = i == 0 ? nullptr : sc->st_list[(i - 1) & 1].p;
+    const uint32_t* count_ptr = i == 0 ? &ctr->n_in_grid : &ctr->st_count[i - 1];
+    StencilOut out;
+    out.fb_list = sc->fb_list.p; out.fb_count = &ctr->fb_count;
+    out.next_list = last ? sc->fb_list.p : sc->st_list[i & 1].p;
+    out.next_count = last ? &ctr->fb_count : &ctr->st_count[i];
+    out.next_is_fallback = last ? 1 : 0;
+    const int combo = kprev * 4 + k;
+    switch (combo) {
+      case 0 * 4 + 1: launch_stencil<0, 1>(c, sc, list, count_ptr, d_keys, out, s); break;
+      case 0 * 4 + 2: launch_stencil<0, 2>(c, sc, list, count_ptr, d_keys, out, s); break;
+      case 0 * 4 + 3: launch_stencil<0, 3>(c, sc, list, count_ptr, d_keys, out, s); break;
+      case 1 * 4 + 2: launch_stencil<1, 2>(c, sc, list, count_ptr, d_keys, out, s); break;
+      case 1 * 4 + 3: launch_stencil<1, 3>(c, sc, list, count_ptr, d_keys, out, s); break;
+      case 2 * 4 + 3: launch_stencil<2, 3>(c, sc, list, count_ptr, d_keys, out, s); break;
+      default: set_error("stencil stages must ascend within 1..3 (got %d after %d)", k, kprev); return PCD_ERR_INVALID;
+    }
+    kprev = k;
+  }
+  return PCD_OK;
+}
 
 template <int G>
 static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t* d_keys, hipStream_t s, bool refine) {
@@ -631,7 +684,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   // fallback list: one slot per query + the chunk slack of every wavefront of the brick kernel (brick_kernel.h)
   // A wavefront leaves a chunk when the next item's unproven queries (<= 8) do not fit: at most 7 of 64 slots stay
   // unused per chunk, so the reserved slots are <= used * 64 / 57 + one chunk per wavefront, used <= Q.
-  const size_t fb_cap = Q + Q / 8 + 8 + (size_t)256 * g_brick_blocks_per_cu * 4 * kFbChunk;
+  const size_t fb_cap = Q + Q / 8 + 8 + (size_t)std::max<unsigned>(256 * g_brick_blocks_per_cu * 4, kStencilBlocks * kStWaves) * kFbChunk;
   PCD_TRY(sc->fb_list.reserve(fb_cap));   // no memset: every reserved slot is written (a query id or the sentinel)
   PCD_TRY(sc->bk_keys.reserve(2 * Q));
   PCD_TRY(sc->bk_vals.reserve(2 * Q));
@@ -663,7 +716,11 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
                        refine ? d_keys : (const uint64_t*)nullptr, (uint32_t)Q, b.nbricks, (uint32_t)b.nb[0],
                        (uint32_t)b.nb[1], sc->items.p, sc->qsorted.p, sc->ksorted.p, sc->fb_list.p, sc->counters.p);
   }
-  {
+  // (the stencil kernel addresses `sorted` with 32-bit byte offsets: clouds of 2^28 records and more take the brick kernel)
+  if (g_nn_kernel == 1 && c->m + kSortedSpare < (1ull << 28)) {
+    ScopedKernelTimer t("nn_stencil", s);
+    PCD_TRY(run_stencil_stages(c, sc, Q, d_keys, s));
+  } else {
     ScopedKernelTimer t("nn_brick", s);
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(div_up(Q, G), 4) + 1, 256 * (uint64_t)g_brick_blocks_per_cu);
     hipLaunchKernelGGL(k_nn_brick<G>, dim3(blocks), dim3(256), 0, s, g, b, c->sorted.p, c->cell_start.p,
@@ -837,6 +894,27 @@ pcd_status pcd_nn_last_stats(pcd_cloud* c, pcd_nn_stats* st) {
   st->fallback_queries = h.fallback_queries;
   st->fallback_points = h.fallback_points;
   st->pair_evals = h.pair_evals;
+  return PCD_OK;
+}
+
+/* tuning hook: which kernel serves the grid path's first stage (1 = stencil stages of half-widths k1 < k2 < k3 cells,
+ * 0 = unused stage; 0 = brick kernel).  Negative kernel: leave everything as it is. */
+pcd_status pcd_nn_set_search(int kernel, int k1, int k2, int k3) {
+  if (kernel < 0) return PCD_OK;
+  PCD_REQUIRE(kernel == 0 || kernel == 1, "kernel must be 0 (brick) or 1 (stencil)");
+  if (kernel == 1) {
+    const int k[3] = {k1, k2, k3};
+    int prev = 0;
+    bool ended = false;
+    for (int i = 0; i < 3; ++i) {
+      if (k[i] <= 0) { ended = true; continue; }
+      PCD_REQUIRE(!ended && k[i] > prev && k[i] <= 3, "stencil half-widths must ascend within 1..3");
+      prev = k[i];
+    }
+    PCD_REQUIRE(k1 > 0, "at least one stencil stage");
+    for (int i = 0; i < 3; ++i) g_st_k[i] = k[i] > 0 ? k[i] : 0;
+  }
+  g_nn_kernel = kernel;
   return PCD_OK;
 }
 

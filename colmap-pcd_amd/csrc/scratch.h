@@ -8,6 +8,8 @@ struct NnCounters {
   unsigned long long brick_groups, staged_points, fallback_queries, fallback_points, pair_evals;
   unsigned int nitems, fb_count;
   unsigned int pad[2];   // pad[0] = length of the squeezed fallback list
+  unsigned int n_in_grid;     // brick-sorted positions 0 .. n_in_grid-1 are the finite queries inside the grid
+  unsigned int st_count[3];   // slots handed out in the stencil stages' output lists (stencil_kernel.h)
 };
 
 struct QueryScratch {
@@ -19,6 +21,7 @@ struct QueryScratch {
   DevBuf<uint64_t> ksorted;    // their incoming keys, same order
   DevBuf<uint4> items;         // {first query, brick x, brick y, brick z | count << 28}
   DevBuf<uint32_t> fb_list, fb_dense;   // fallback list as the brick kernel fills it (chunked) / squeezed
+  DevBuf<uint32_t> st_list[2];          // stencil stages' lists of unproven queries (sorted positions, chunked)
   DevBuf<NnCounters> counters;
   DevBuf<char> tmp;
   DevBuf<double> d_q;          // staging of host queries

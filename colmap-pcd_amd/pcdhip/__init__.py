@@ -518,6 +518,11 @@ def set_nn_tuning(brick_cells=0, halo_cells=-1, collect_stats=0):
     lib().pcd_nn_set_tuning(int(brick_cells), int(halo_cells), int(collect_stats))
 
 
+def set_nn_search(kernel=1, k1=1, k2=2, k3=0):
+    """first stage of the grid path: kernel 1 = stencil stages of half-widths k1 < k2 < k3 cells (0 = unused), 0 = brick kernel"""
+    _check(lib().pcd_nn_set_search(int(kernel), int(k1), int(k2), int(k3)))
+
+
 def profile_enable(on=True):
     lib().pcd_profile_enable(int(on))
 

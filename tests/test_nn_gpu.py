@@ -285,3 +285,30 @@ def test_far_from_origin(gpu, offset):
     _check_exact(c.nn(q, gpu.NN_GRID), c.nn(q, gpu.NN_BRUTEFORCE), f"grid vs brute force at offset {offset}")
     _check_exact(c.nn(q), c.nn(q, gpu.NN_BRUTEFORCE), f"auto vs brute force at offset {offset}")
     c.close()
+
+
+@pytest.mark.parametrize("stages", [(1, 0, 0), (1, 2, 0), (1, 2, 3), (1, 3, 0), (2, 3, 0), (3, 0, 0)])
+def test_stencil_stage_cascades(gpu, oracle, stages):
+    """The per-query stencil stages (csrc/stencil_kernel.h) as first stage of the grid path: every cascade of cube
+    half-widths must give the oracle's keys bit for bit -- on a surface cloud, on exact ties (duplicates, the lattice)
+    and on a cloud with cells far denser than a stage's step table (those queries take the overflow route to the
+    pyramid search)."""
+    rng = np.random.default_rng(31)
+    cases = dict(_clouds())
+    dense, dn = synth.cloud_uniform(30000, seed=5, box=np.array([6.0, 6.0, 6.0]))
+    dense[:12000] = dense[0] + rng.normal(0, 2e-3, (12000, 3)).astype(np.float32)   # 12 k points inside one cell
+    cases["dense_cell"] = (dense, dn)
+    lat = np.stack(np.meshgrid(np.arange(40), np.arange(30), np.arange(20), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.25
+    cases["lattice"] = (lat, np.ones_like(lat))
+    try:
+        gpu.set_nn_search(1, *stages)
+        for name, (xyz, nrm) in cases.items():
+            q = synth.queries(xyz, 6000, seed=7)
+            q[:300] = xyz[rng.integers(0, xyz.shape[0], 300)].astype(np.float64)
+            if name == "lattice":
+                q[300:900] = np.round(q[300:900] / 0.125) * 0.125      # midway between lattice points: exact ties
+            c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+            _check_exact(c.nn(q, gpu.NN_GRID), oracle.nn_bruteforce(xyz, q), f"stencil{stages}/{name}")
+            c.close()
+    finally:
+        gpu.set_nn_search(0)
