@@ -61,16 +61,22 @@ constexpr uint64_t kSmallBatch = 65536;
 // ------------------------------------------------------------ brick math ---
 struct BrickParams {
   int B, R;        // brick edge in cells (y, z), halo in cells
+  int S;           // bricks start S cells before the grid origin in y and z: brick b = cells [b B - S, b B - S + B).
+                   //   B = 2, R = 1, S = 1 puts the halo region [2b - 2, 2b + 2) on whole cell quads: 2 x 2 quad rows
   int Bx;          // brick length along x in cells (the rows of the region run along x)
   int nb[3];       // bricks per axis
   uint32_t nbricks;
 };
 
-static BrickParams make_bricks(const GridParams& g, int B, int Bx, int R) {
+static BrickParams make_bricks(const GridParams& g, int B, int Bx, int R, int S = 0) {
   BrickParams b;
-  b.B = B; b.R = R; b.Bx = Bx;
+  b.B = B; b.R = R; b.Bx = Bx; b.S = S;
   uint64_t n = 1;
-  for (int d = 0; d < 3; ++d) { const int e = d == 0 ? Bx : B; b.nb[d] = (g.dims[d] + e - 1) / e; n *= (uint64_t)b.nb[d]; }
+  for (int d = 0; d < 3; ++d) {
+    const int e = d == 0 ? Bx : B, sh = d == 0 ? 0 : S;
+    b.nb[d] = (g.dims[d] + sh + e - 1) / e;
+    n *= (uint64_t)b.nb[d];
+  }
   b.nbricks = (uint32_t)n;
   return b;
 }
@@ -215,7 +221,7 @@ __global__ void k_brick_keys(const float4* __restrict__ qf4, uint64_t Q, GridPar
     const int cy = cell_coord_raw(q.y, g.origin[1], g.inv_h, g.dims[1]);
     const int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
     const bool in = cx >= 0 && cx < g.dims[0] && cy >= 0 && cy < g.dims[1] && cz >= 0 && cz < g.dims[2];
-    bid = in ? (uint32_t)(((uint64_t)(cz / b.B) * b.nb[1] + (cy / b.B)) * b.nb[0] + (cx / b.Bx)) : b.nbricks;
+    bid = in ? (uint32_t)(((uint64_t)((cz + b.S) / b.B) * b.nb[1] + ((cy + b.S) / b.B)) * b.nb[0] + (cx / b.Bx)) : b.nbricks;
   }
   keys[i] = bid;
   vals[i] = (uint32_t)i;
@@ -618,7 +624,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
 // the hardware's workgroup dispatch as the load balancer (query costs spread 1:4).  2048 / 4096 / 16384 / 65536
 // workgroups: 0.384 / 0.387 / 0.368 / 0.369 ms at workload M, 0.136 / 0.125 / 0.126 / 0.125 ms on an eighth of it.
 constexpr unsigned g_fb_max_blocks = 16384;
-static int g_brick_B = 2, g_brick_R = 2, g_collect_stats = 0, g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
+static int g_brick_B = 2, g_brick_R = 2, g_brick_S = 0, g_collect_stats = 0, g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
 // first stage of the grid path: 0 = brick kernel (brick_kernel.h), 1 = per-query stencil stages (stencil_kernel.h).
 // The stencil stages halve the point-query pairs (590 instead of 1 306 per query on workload M) but load every
 // point once PER QUERY instead of once per brick: 9.4 GB through the vector L1s per batch against the brick kernel's
@@ -628,10 +634,10 @@ static int g_nn_kernel = 0;
 static int g_st_k[3] = {1, 2, 0};            // cube half-widths of the stencil stages in cells (ascending; 0 = unused)
 constexpr unsigned kStencilBlocks = 256 * (16 / kStWaves);  // persistent grid: 16 wavefronts per CU (4 per SIMD) on 256 CUs
 
-template <int KPREV, int K>
+template <int KPREV, int K, int BRICK = 0>
 static void launch_stencil(pcd_cloud* c, QueryScratch* sc, const uint32_t* list, const uint32_t* count_ptr,
-                           uint64_t* d_keys, const StencilOut& out, hipStream_t s) {
-  hipLaunchKernelGGL((k_nn_stencil<KPREV, K>), dim3(kStencilBlocks), dim3(64 * kStWaves), 0, s, c->grid, c->sorted.p,
+                           uint64_t* d_keys, const StencilOut& out, hipStream_t s, const BrickParams& b = BrickParams{}) {
+  hipLaunchKernelGGL((k_nn_stencil<KPREV, K, BRICK>), dim3(kStencilBlocks), dim3(64 * kStWaves), 0, s, c->grid, b, c->sorted.p,
                      c->cell_start.p, sc->qsorted.p, sc->ksorted.p, list, count_ptr, d_keys, out, sc->counters.p,
                      g_collect_stats);
 }
@@ -678,7 +684,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   if ((B + 2 * R) * (B + 2 * R) > kMaxRows) { B = 2; R = 2; }
   // x-long bricks (Bx = 2B, 3B, 4B: fewer, fuller groups but a longer region per query) were measured on workload M:
   // 0.638 / 0.698 / 0.768 ms against 0.633 ms for cubes (profiles/r02_nn_config_sweeps.txt)
-  const BrickParams b = make_bricks(g, B, B, R);
+  const BrickParams b = make_bricks(g, B, B, R, g_brick_S);
   PCD_TRY(sc->qsorted.reserve(Q));
   PCD_TRY(sc->ksorted.reserve(Q));
   // fallback list: one slot per query + the chunk slack of every wavefront of the brick kernel (brick_kernel.h)
@@ -721,10 +727,26 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     ScopedKernelTimer t("nn_stencil", s);
     PCD_TRY(run_stencil_stages(c, sc, Q, d_keys, s));
   } else {
-    ScopedKernelTimer t("nn_brick", s);
-    const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(div_up(Q, G), 4) + 1, 256 * (uint64_t)g_brick_blocks_per_cu);
-    hipLaunchKernelGGL(k_nn_brick<G>, dim3(blocks), dim3(256), 0, s, g, b, c->sorted.p, c->cell_start.p,
-                       sc->qsorted.p, sc->ksorted.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p, g_collect_stats);
+    // g_nn_kernel == 2: the brick kernel with a small region, then ONE ball-clipped stencil stage over the +-3 cube of
+    // every query the brick kernel could not prove (stencil_kernel.h, BRICK = 1)
+    const bool second = g_nn_kernel == 2 && c->m + kSortedSpare < (1ull << 28);
+    const size_t cap = Q + Q / 8 + 64 + (size_t)256 * g_brick_blocks_per_cu * 4 * kFbChunk;
+    if (second) PCD_TRY(sc->st_list[0].reserve(cap));
+    {
+      ScopedKernelTimer t("nn_brick", s);
+      const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(div_up(Q, G), 4) + 1, 256 * (uint64_t)g_brick_blocks_per_cu);
+      hipLaunchKernelGGL(k_nn_brick<G>, dim3(blocks), dim3(256), 0, s, g, b, c->sorted.p, c->cell_start.p,
+                         sc->qsorted.p, sc->ksorted.p, sc->items.p, sc->counters.p, d_keys,
+                         second ? sc->st_list[0].p : sc->fb_list.p,
+                         second ? &sc->counters.p->st_count[0] : &sc->counters.p->fb_count, g_collect_stats | (second ? 2 : 0));
+    }
+    if (second) {
+      ScopedKernelTimer t("nn_ball", s);
+      StencilOut out;
+      out.fb_list = sc->fb_list.p; out.fb_count = &sc->counters.p->fb_count;
+      out.next_list = sc->fb_list.p; out.next_count = &sc->counters.p->fb_count; out.next_is_fallback = 1;
+      launch_stencil<0, 3, 1>(c, sc, sc->st_list[0].p, &sc->counters.p->st_count[0], d_keys, out, s, b);
+    }
   }
   {
     ScopedKernelTimer t("nn_fallback", s);
@@ -901,7 +923,7 @@ pcd_status pcd_nn_last_stats(pcd_cloud* c, pcd_nn_stats* st) {
  * 0 = unused stage; 0 = brick kernel).  Negative kernel: leave everything as it is. */
 pcd_status pcd_nn_set_search(int kernel, int k1, int k2, int k3) {
   if (kernel < 0) return PCD_OK;
-  PCD_REQUIRE(kernel == 0 || kernel == 1, "kernel must be 0 (brick) or 1 (stencil)");
+  PCD_REQUIRE(kernel >= 0 && kernel <= 2, "kernel must be 0 (brick), 1 (stencil) or 2 (brick + ball-clipped stencil stage)");
   if (kernel == 1) {
     const int k[3] = {k1, k2, k3};
     int prev = 0;
@@ -915,6 +937,12 @@ pcd_status pcd_nn_set_search(int kernel, int k1, int k2, int k3) {
     for (int i = 0; i < 3; ++i) g_st_k[i] = k[i] > 0 ? k[i] : 0;
   }
   g_nn_kernel = kernel;
+  return PCD_OK;
+}
+
+pcd_status pcd_nn_set_brick_shift(int shift) {
+  PCD_REQUIRE(shift == 0 || shift == 1, "shift must be 0 or 1");
+  g_brick_S = shift;
   return PCD_OK;
 }
 

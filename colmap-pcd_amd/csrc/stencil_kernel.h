@@ -65,8 +65,14 @@ struct StencilOut {
   int next_is_fallback;
 };
 
-template <int KPREV, int K>
-__global__ __launch_bounds__(64 * kStWaves, 4) void k_nn_stencil(GridParams g, const float4* __restrict__ sorted,
+// BRICK = 1: the stage runs behind the brick kernel (nn.hip run_grid): what has been scanned already is the query's
+// brick region (whole quad rows over the region's x-range, brick_kernel.h brick_load_meta), the tentative best
+// distance d_t the brick kernel found comes in as the prior key, and every quad row is CLIPPED TO THE BALL of radius
+// d_t around the query -- a point farther than d_t cannot be the nearest neighbour, so the rows the ball misses are
+// skipped and the others shrink to the cells its x-extent touches (rounding: radius widened by 2e-6 relative and by the
+// binning slack; cell bounds widened by the slack).  KPREV is unused then.
+template <int KPREV, int K, int BRICK>
+__global__ __launch_bounds__(64 * kStWaves, 4) void k_nn_stencil(GridParams g, BrickParams b, const float4* __restrict__ sorted,
                                                         const uint32_t* __restrict__ cell_start,
                                                         const float4* __restrict__ qsorted,
                                                         uint64_t* __restrict__ ksorted,
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(64 * kStWaves, 4) void k_nn_stencil(GridParams g, c
                                                         NnCounters* __restrict__ ctr, int collect_stats) {
   static_assert(K >= 1 && K <= 3 && KPREV < K, "one quad row per lane of a 16-lane group: (K + 1)^2 <= 16");
   constexpr int NQR = K + 1;   // quad rows per axis of the +-K cube: ((c + K) >> 1) - ((c - K) >> 1) + 1 for every c
+  constexpr bool TWO = KPREV > 0 || BRICK;   // a quad row may have two x-ranges (left and right of the scanned part)
   __shared__ __attribute__((aligned(16))) uint32_t s_tbl[kStWaves][kStQ][kStCap];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -87,10 +94,8 @@ __global__ __launch_bounds__(64 * kStWaves, 4) void k_nn_stencil(GridParams g, c
   unsigned long long st_steps = 0, st_q = 0;
 
   // Work split.  A BLOCK ITERATION = kStWaves consecutive wavefront iterations = 4 kStWaves queries that are neighbours
-  // in the cell-sorted order: the wavefronts of a workgroup stream overlapping stencils at the same time, so the CU's
-  // vector L1 serves most of their loads (one wavefront per 4 queries scattered over the grid made every stencil an L2
-  // stream: 21 TB/s of cache traffic and nothing else bounded the kernel).  Blocks b, b+8, ... share an XCD: each of
-  // the 8 classes walks its own contiguous eighth of the block iterations, in chunks of kStChunk per workgroup.
+  // in the cell-sorted order.  Blocks b, b+8, ... share an XCD: each of the 8 classes walks its own contiguous eighth
+  // of the block iterations, in chunks of kStChunk per workgroup.
   const uint32_t nbi = (niter + kStWaves - 1) / kStWaves;
   const uint32_t ncls = (gridDim.x & 7u) == 0 ? 8u : 1u;
   const uint32_t cls = ncls == 8u ? (blockIdx.x & 7u) : 0u, bic = ncls == 8u ? (blockIdx.x >> 3) : blockIdx.x;
@@ -114,20 +119,46 @@ __global__ __launch_bounds__(64 * kStWaves, 4) void k_nn_stencil(GridParams g, c
     const int ry = sub % NQR, rz = sub / NQR;
     const int yq = yqa + ry, zq = zqa + rz;
     const bool row_ok = valid && sub < NQR * NQR && yq >= 0 && yq < g.qdims[0] && zq >= 0 && zq < g.qdims[1];
-    bool inner = false;
-    if (KPREV > 0)
-      inner = yq >= ((cy - KPREV) >> 1) && yq <= ((cy + KPREV) >> 1) && zq >= ((cz - KPREV) >> 1) && zq <= ((cz + KPREV) >> 1);
     const int nx = g.dims[0];
-    const int xa0 = max(cx - K, 0), xb1 = min(cx + K + 1, nx);
-    const int xa1 = inner ? max(cx - KPREV, 0) : xb1;
-    const int xb0 = inner ? min(cx + KPREV + 1, nx) : xb1;
+    int xlo = max(cx - K, 0), xhi = min(cx + K + 1, nx);   // the cube's cells along x
+    bool inner = false;
+    int ix0 = 0, ix1 = 0;                                  // x-cells of an inner row that are scanned already
+    if (BRICK) {
+      const int bx = cx / b.Bx, by = (cy + b.S) / b.B, bz = (cz + b.S) / b.B;
+      const int ry0 = by * b.B - b.S - b.R, ry1 = ry0 + b.B + 2 * b.R, rz0 = bz * b.B - b.S - b.R, rz1 = rz0 + b.B + 2 * b.R;
+      inner = 2 * yq + 2 > ry0 && 2 * yq < ry1 && 2 * zq + 2 > rz0 && 2 * zq < rz1;   // the brick kernel takes whole quads
+      ix0 = max(bx * b.Bx - b.R, 0); ix1 = min(bx * b.Bx + b.Bx + b.R, nx);
+      // clip the row to the ball of the tentative distance
+      const double dt = (double)__uint_as_float((uint32_t)(prior >> 32));
+      const double sl = (double)g.slack, h = (double)g.h;
+      const double r = sqrt(dt * (1.0 + 4e-6)) + sl, r2 = r * r;   // inf for a query without a tentative result
+      const double ya = (double)g.origin[1] + (double)(2 * yq) * h - sl, yb = (double)g.origin[1] + (double)(2 * yq + 2) * h + sl;
+      const double za = (double)g.origin[2] + (double)(2 * zq) * h - sl, zb = (double)g.origin[2] + (double)(2 * zq + 2) * h + sl;
+      const double dy = fmax(fmax(ya - (double)qr.y, (double)qr.y - yb), 0.0), dz = fmax(fmax(za - (double)qr.z, (double)qr.z - zb), 0.0);
+      const double dyz2 = dy * dy + dz * dz;
+      if (dyz2 > r2) {
+        xhi = xlo;                                         // the ball misses the row
+      } else {
+        const double ex = sqrt(r2 - dyz2) + 2.0 * sl;      // half-extent along x (inf stays inf)
+        const double ca = floor(((double)qr.x - ex - (double)g.origin[0]) / h), cb2 = floor(((double)qr.x + ex - (double)g.origin[0]) / h);
+        xlo = max(xlo, (int)fmin(fmax(ca, -1.0), (double)nx));
+        xhi = min(xhi, (int)fmin(fmax(cb2, -1.0), (double)nx) + 1);
+        xhi = max(xhi, xlo);
+      }
+    } else if (KPREV > 0) {
+      inner = yq >= ((cy - KPREV) >> 1) && yq <= ((cy + KPREV) >> 1) && zq >= ((cz - KPREV) >> 1) && zq <= ((cz + KPREV) >> 1);
+      ix0 = max(cx - KPREV, 0); ix1 = min(cx + KPREV + 1, nx);
+    }
+    const int xa0 = xlo, xb1 = xhi;
+    const int xa1 = inner ? min(max(ix0, xlo), xhi) : xhi;
+    const int xb0 = inner ? min(max(ix1, xlo), xhi) : xhi;
     const uint32_t rowbase = (uint32_t)quad_row_base(g, row_ok ? yq : 0, row_ok ? zq : 0);
     // every lane issues every load (clamped rows, results masked): no loads under divergent branches
     const uint32_t sA = cell_start[rowbase + 4u * (uint32_t)xa0], eA = cell_start[rowbase + 4u * (uint32_t)xa1];
     uint32_t sB = 0, eB = 0;
-    if (KPREV > 0) { sB = cell_start[rowbase + 4u * (uint32_t)xb0]; eB = cell_start[rowbase + 4u * (uint32_t)xb1]; }
+    if (TWO) { sB = cell_start[rowbase + 4u * (uint32_t)xb0]; eB = cell_start[rowbase + 4u * (uint32_t)xb1]; }
     const uint32_t nA = row_ok ? (eA - sA + 15u) >> 4 : 0u;
-    const uint32_t nB = (KPREV > 0 && row_ok) ? (eB - sB + 15u) >> 4 : 0u;
+    const uint32_t nB = (TWO && row_ok) ? (eB - sB + 15u) >> 4 : 0u;
     const uint32_t n = nA + nB;
     // ---- steps of the group: prefix over its 16 lanes, total per group, longest group of the wavefront --------
     uint32_t inc = n;

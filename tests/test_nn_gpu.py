@@ -312,3 +312,33 @@ def test_stencil_stage_cascades(gpu, oracle, stages):
             c.close()
     finally:
         gpu.set_nn_search(0)
+
+
+@pytest.mark.parametrize("brs", [(2, 1, 1), (2, 2, 0), (2, 1, 0), (4, 1, 1)])
+def test_brick_then_ball_clipped_stage(gpu, oracle, brs):
+    """Grid path as brick kernel with a small halo region + one ball-clipped stencil stage over the +-3 cube
+    (pcd_nn_set_search(2)): bit-equal to the oracle for shifted and unshifted bricks, incl. ties and dense cells."""
+    rng = np.random.default_rng(32)
+    cases = dict(_clouds())
+    dense, dn = synth.cloud_uniform(30000, seed=5, box=np.array([6.0, 6.0, 6.0]))
+    dense[:12000] = dense[0] + rng.normal(0, 2e-3, (12000, 3)).astype(np.float32)
+    cases["dense_cell"] = (dense, dn)
+    lat = np.stack(np.meshgrid(np.arange(40), np.arange(30), np.arange(20), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.25
+    cases["lattice"] = (lat, np.ones_like(lat))
+    try:
+        gpu.set_nn_search(2)
+        gpu.set_nn_tuning(brs[0], brs[1], 0)
+        gpu.set_brick_shift(brs[2])
+        for name, (xyz, nrm) in cases.items():
+            for sigma in (0.25, 1.0):
+                q = synth.queries(xyz, 6000, seed=7, sigma=sigma)
+                q[:300] = xyz[rng.integers(0, xyz.shape[0], 300)].astype(np.float64)
+                if name == "lattice":
+                    q[300:900] = np.round(q[300:900] / 0.125) * 0.125
+                c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+                _check_exact(c.nn(q, gpu.NN_GRID), oracle.nn_bruteforce(xyz, q), f"brick+ball{brs}/{name}/sigma{sigma}")
+                c.close()
+    finally:
+        gpu.set_nn_search(0)
+        gpu.set_nn_tuning(2, 2, 0)
+        gpu.set_brick_shift(0)
