@@ -369,6 +369,248 @@ __global__ __launch_bounds__(256) void k_brick_emit(const uint32_t* __restrict__
   if (blockIdx.x == gridDim.x - 1 && tid == 0) ctr->nitems = tile_off + total;
 }
 
+// ------------------------------------------- brick bookkeeping, counting sort ---
+// Four launches instead of the radix sort's seven (round 2: 0.17 ms at Q = 1 M, three Onesweep digit passes at ~29 us
+// each whatever the size).  Per cloud and brick geometry, once: a SLOT for every brick whose halo region holds at
+// least one cloud point (k_brick_occupied + an exclusive scan; slots ascend with the brick id); a query in a brick
+// without a slot has nothing within the halo and goes straight to the exact fallback -- which is where the brick
+// kernel would have sent it after walking an empty region.  Per batch a two-level counting sort on the slot:
+//   k_bk_slots    query -> sort key (brick id) or "fallback" (outside the grid / brick with an empty halo region: those
+//                 are appended to the chunked fallback list here); histogram of the COARSE keys (id >> shift, at most
+//                 4096 buckets): LDS histogram per workgroup, merged with global atomics.
+//   k_bk_scatter  every workgroup scans the histogram into bucket starts itself; tiles of 4096 queries: rank inside the
+//                 tile by LDS atomics, one global atomic per (tile, bucket) for the tile's place in the bucket,
+//                 (key, query) pairs written bucket by bucket.
+//   k_bk_count    one workgroup per coarse bucket: queries per FINE key (low bits) in LDS -> the bucket's item count.
+//   k_bk_emit     one workgroup per coarse bucket: the same counting sort again, now with the item base known (sum
+//                 of the item counts to the left: items stay in brick order, which the XCD-aware walk of k_nn_brick
+//                 is worth 0.04 ms for), then the brick-sorted query records, their incoming keys and the work
+//                 items (G queries of one brick each).
+// (No workgroup waits for another one: a look-back over per-bucket descriptors needs agent-scope release / acquire to
+//  cross the XCDs' L2s -- with relaxed polling the descriptors never arrived -- and at that price was slower than this
+//  fourth launch.)
+// Queries of one brick arrive in any order (LDS / global atomics): WHICH queries share a work item varies from run to
+// run, every query's result does not.
+constexpr uint32_t kSlotFallback = 0xFFFFFFFEu;   // query: finite, but outside the grid or in a brick without a slot
+constexpr uint32_t kSlotSkip = 0xFFFFFFFFu;       // query: not finite
+constexpr uint32_t kBkMaxCoarse = 4096, kBkMaxFine = 2048, kBkTileQ = 4096;
+
+// one thread per brick: does the halo region (whole quad rows, as brick_load_meta walks them) hold any point?
+__global__ void k_brick_occupied(GridParams g, BrickParams b, const uint32_t* __restrict__ cell_start,
+                                 uint32_t* __restrict__ flag) {
+  const uint32_t bid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bid >= b.nbricks) return;
+  const int bx = (int)(bid % (uint32_t)b.nb[0]), by = (int)((bid / (uint32_t)b.nb[0]) % (uint32_t)b.nb[1]),
+            bz = (int)(bid / ((uint32_t)b.nb[0] * (uint32_t)b.nb[1]));
+  const int x0 = max(bx * b.Bx - b.R, 0), x1 = min(bx * b.Bx + b.Bx + b.R, g.dims[0]);
+  const int y0 = max(by * b.B - b.S - b.R, 0), y1 = min(by * b.B - b.S + b.B + b.R, g.dims[1]);
+  const int z0 = max(bz * b.B - b.S - b.R, 0), z1 = min(bz * b.B - b.S + b.B + b.R, g.dims[2]);
+  uint32_t any = 0;
+  if (x0 < x1 && y0 < y1 && z0 < z1)
+    for (int zq = z0 >> 1; zq < (z1 + 1) >> 1; ++zq)
+      for (int yq = y0 >> 1; yq < (y1 + 1) >> 1; ++yq) {
+        const uint64_t rb = quad_row_base(g, yq, zq);
+        any |= cell_start[rb + 4 * (uint64_t)x1] - cell_start[rb + 4 * (uint64_t)x0];
+      }
+  flag[bid] = any ? 1u : 0u;
+}
+// 1 bit per brick: the halo region holds a point (32 bricks per thread; 580 KB for workload M's 4.65 M bricks, cache
+// resident -- a 4-byte slot per brick made the per-query lookup a 128 MB gather)
+__global__ void k_brick_bitmap(const uint32_t* __restrict__ flag, uint32_t nbricks, uint32_t* __restrict__ bits) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w * 32u >= nbricks) return;
+  uint32_t m = 0;
+  for (uint32_t k = 0; k < 32u && w * 32u + k < nbricks; ++k) m |= (flag[w * 32u + k] ? 1u : 0u) << k;
+  bits[w] = m;
+}
+
+// block-wide exclusive scan of one value per thread (NW wavefronts); returns the exclusive prefix, *total in every thread
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w /*[NW]*/, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t inc = wave_scan_add_u32(v);
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (uint32_t w = 0; w < (uint32_t)NW; ++w) { if (w < wave) base += s_w[w]; tot += s_w[w]; }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_w, uint32_t* total) {
+  return block_excl_scan<4>(v, s_w, total);
+}
+
+__global__ __launch_bounds__(1024) void k_bk_slots(const float4* __restrict__ qf4, uint32_t Q, GridParams g, BrickParams b,
+                                                   const uint32_t* __restrict__ brick_slot, uint32_t shift, uint32_t ncoarse,
+                                                   uint32_t* __restrict__ qslot, uint32_t* __restrict__ chist,
+                                                   uint32_t* __restrict__ fb_list, NnCounters* __restrict__ ctr) {
+  // few, large workgroups: every workgroup merges its whole LDS histogram into the global one with atomics
+  // (1024 workgroups x 2048 buckets = 2 M global atomics made this kernel 145 us)
+  __shared__ uint32_t s_h[kBkMaxCoarse];
+  for (uint32_t c = threadIdx.x; c < ncoarse; c += 1024) s_h[c] = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t fb_base = 0, fb_left = 0;   // this wavefront's chunk of the fallback list
+  for (uint32_t i0 = blockIdx.x * 1024u; i0 < Q; i0 += gridDim.x * 1024u) {
+    const uint32_t i = i0 + threadIdx.x;
+    uint32_t s = kSlotSkip;
+    if (i < Q) {
+      const float4 q = qf4[i];
+      if (q.w != 0.f) {
+        const int cx = cell_coord_raw(q.x, g.origin[0], g.inv_h, g.dims[0]);
+        const int cy = cell_coord_raw(q.y, g.origin[1], g.inv_h, g.dims[1]);
+        const int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
+        const bool in = cx >= 0 && cx < g.dims[0] && cy >= 0 && cy < g.dims[1] && cz >= 0 && cz < g.dims[2];
+        s = kSlotFallback;
+        if (in) {
+          const uint32_t bid = (uint32_t)(((uint64_t)((cz + b.S) / b.B) * b.nb[1] + ((cy + b.S) / b.B)) * b.nb[0] + (cx / b.Bx));
+          if ((brick_slot[bid >> 5] >> (bid & 31u)) & 1u) { s = bid; atomicAdd(&s_h[bid >> shift], 1u); }
+        }
+      }
+      qslot[i] = s;
+    }
+    const unsigned long long um = __ballot(s == kSlotFallback);
+    if (um) {
+      // up to 64 entries at once: the first fb_left of them finish the current chunk, the others open the next one
+      const uint32_t k = (uint32_t)__popcll(um), rank = (uint32_t)__popcll(um & ((1ull << lane) - 1));
+      const uint32_t old_base = fb_base, old_left = fb_left;
+      uint32_t new_base = 0;
+      if (k > old_left) {
+        uint32_t nb = 0;
+        if (lane == 0) nb = atomicAdd(&ctr->fb_count, 64u);
+        new_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+      }
+      if (s == kSlotFallback) fb_list[rank < old_left ? old_base + rank : new_base + (rank - old_left)] = i;
+      if (k > old_left) { fb_base = new_base + (k - old_left); fb_left = 64u - (k - old_left); }
+      else { fb_base += k; fb_left -= k; }
+    }
+  }
+  if (lane < fb_left) fb_list[fb_base + lane] = 0xFFFFFFFFu;
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < ncoarse; c += 1024)
+    if (s_h[c]) atomicAdd(&chist[c], s_h[c]);
+}
+
+__global__ __launch_bounds__(1024) void k_bk_scatter(const uint32_t* __restrict__ qslot, uint32_t Q, uint32_t shift,
+                                                     uint32_t ncoarse, const uint32_t* __restrict__ chist,
+                                                     uint32_t* __restrict__ cstart, uint32_t* __restrict__ ccur,
+                                                     uint32_t* __restrict__ pslot, uint32_t* __restrict__ pqid,
+                                                     NnCounters* __restrict__ ctr) {
+  __shared__ uint32_t s_h[kBkMaxCoarse], s_start[kBkMaxCoarse], s_w[16];
+  // bucket starts: every workgroup scans the (at most 4096-entry) histogram itself; workgroup 0 keeps the result
+  {
+    const uint32_t per = (ncoarse + 1023u) / 1024u, c0 = threadIdx.x * per;   // per <= 4
+    uint32_t h[4] = {0, 0, 0, 0}, sum = 0;
+    for (uint32_t k = 0; k < per && c0 + k < ncoarse; ++k) { h[k] = chist[c0 + k]; sum += h[k]; }
+    uint32_t total;
+    uint32_t base = block_excl_scan<16>(sum, s_w, &total);
+    for (uint32_t k = 0; k < per && c0 + k < ncoarse; ++k) {
+      s_start[c0 + k] = base;
+      if (blockIdx.x == 0) cstart[c0 + k] = base;
+      base += h[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cstart[ncoarse] = total; ctr->n_in_grid = total; }
+  }
+  for (uint32_t c = threadIdx.x; c < ncoarse; c += 1024) s_h[c] = 0;
+  __syncthreads();
+  const uint32_t i0 = blockIdx.x * kBkTileQ + threadIdx.x;
+  uint32_t sl[4], lr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t i = i0 + k * 1024u;
+    sl[k] = i < Q ? qslot[i] : kSlotSkip;
+    lr[k] = sl[k] < kSlotFallback ? atomicAdd(&s_h[sl[k] >> shift], 1u) : 0u;   // rank inside the tile
+  }
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < ncoarse; c += 1024) {
+    const uint32_t n = s_h[c];
+    s_h[c] = s_start[c] + (n ? atomicAdd(&ccur[c], n) : 0u);     // the tile's place in the bucket (cursors start at 0)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (sl[k] < kSlotFallback) {
+      const uint32_t p = s_h[sl[k] >> shift] + lr[k];
+      pslot[p] = sl[k];
+      pqid[p] = i0 + k * 1024u;
+    }
+}
+
+// work items of every coarse bucket: one workgroup per bucket counts the bucket's queries per fine key in LDS
+template <int G>
+__global__ __launch_bounds__(256) void k_bk_count(uint32_t shift, const uint32_t* __restrict__ cstart,
+                                                  const uint32_t* __restrict__ pslot, uint32_t* __restrict__ bitems) {
+  __shared__ uint32_t s_cnt[kBkMaxFine], s_w[4];
+  const uint32_t nfine = 1u << shift, mask = nfine - 1u;
+  const uint32_t beg = cstart[blockIdx.x], end = cstart[blockIdx.x + 1];
+  if (beg == end) { if (threadIdx.x == 0) bitems[blockIdx.x] = 0; return; }
+  for (uint32_t f = threadIdx.x; f < nfine; f += 256) s_cnt[f] = 0;
+  __syncthreads();
+  for (uint32_t p = beg + threadIdx.x; p < end; p += 256) atomicAdd(&s_cnt[pslot[p] & mask], 1u);
+  __syncthreads();
+  uint32_t ai = 0;
+  for (uint32_t f = threadIdx.x; f < nfine; f += 256) ai += (s_cnt[f] + G - 1) / G;
+  uint32_t ti;
+  (void)block_excl_scan_256(ai, s_w, &ti);
+  if (threadIdx.x == 0) bitems[blockIdx.x] = ti;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_bk_emit(const float4* __restrict__ qf4, const uint64_t* __restrict__ keys_in,
+                                                 GridParams g, BrickParams b, uint32_t shift,
+                                                 const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ pslot,
+                                                 const uint32_t* __restrict__ pqid, const uint32_t* __restrict__ bitems,
+                                                 uint32_t* __restrict__ chist, uint32_t* __restrict__ ccur,
+                                                 uint4* __restrict__ items, float4* __restrict__ qsorted,
+                                                 uint64_t* __restrict__ ksorted, NnCounters* __restrict__ ctr) {
+  __shared__ uint32_t s_cnt[kBkMaxFine], s_off[kBkMaxFine], s_ioff[kBkMaxFine], s_cur[kBkMaxFine], s_w[4];
+  const uint32_t nfine = 1u << shift, mask = nfine - 1u;
+  const uint32_t beg = cstart[blockIdx.x], end = cstart[blockIdx.x + 1];
+  // item base = items of all buckets to the left, in bucket order = brick order (the XCD-aware walk of k_nn_brick
+  // depends on it): summed from k_bk_count's per-bucket totals -- no atomics, no waiting on other workgroups
+  uint32_t acc = 0;
+  for (uint32_t c = threadIdx.x; c < blockIdx.x; c += 256) acc += bitems[c];
+  uint32_t ibase;
+  (void)block_excl_scan_256(acc, s_w, &ibase);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ctr->nitems = ibase + bitems[blockIdx.x];
+  if (threadIdx.x == 0) { chist[blockIdx.x] = 0; ccur[blockIdx.x] = 0; }   // clean for the next batch
+  if (beg == end) return;
+  for (uint32_t f = threadIdx.x; f < nfine; f += 256) { s_cnt[f] = 0; s_cur[f] = 0; }
+  __syncthreads();
+  for (uint32_t p = beg + threadIdx.x; p < end; p += 256) atomicAdd(&s_cnt[pslot[p] & mask], 1u);
+  __syncthreads();
+  // exclusive prefixes of the query counts and of the item counts over the bucket's fine keys
+  const uint32_t per = (nfine + 255u) / 256u, f0 = threadIdx.x * per;
+  {
+    uint32_t aq = 0, ai = 0;
+    for (uint32_t f = f0; f < min(f0 + per, nfine); ++f) { aq += s_cnt[f]; ai += (s_cnt[f] + G - 1) / G; }
+    uint32_t tq, ti;
+    uint32_t bq = block_excl_scan_256(aq, s_w, &tq);
+    uint32_t bi = block_excl_scan_256(ai, s_w, &ti);
+    for (uint32_t f = f0; f < min(f0 + per, nfine); ++f) { s_off[f] = bq; s_ioff[f] = bi; bq += s_cnt[f]; bi += (s_cnt[f] + G - 1) / G; }
+    __syncthreads();
+  }
+  for (uint32_t p = beg + threadIdx.x; p < end; p += 256) {
+    const uint32_t f = pslot[p] & mask, i = pqid[p];
+    const uint32_t r = atomicAdd(&s_cur[f], 1u);
+    float4 q = qf4[i];
+    const uint32_t pos = beg + s_off[f] + r;
+    if (r % (uint32_t)G == 0u) {   // first query of a work item: G consecutive positions of one brick
+      const int cx = cell_coord_raw(q.x, g.origin[0], g.inv_h, g.dims[0]);
+      const int cy = cell_coord_raw(q.y, g.origin[1], g.inv_h, g.dims[1]);
+      const int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
+      const uint32_t left = s_cnt[f] - r;
+      items[ibase + s_ioff[f] + r / (uint32_t)G] =
+          make_uint4(pos, (uint32_t)(cx / b.Bx), (uint32_t)((cy + b.S) / b.B),
+                     (uint32_t)((cz + b.S) / b.B) | ((left < (uint32_t)G ? left : (uint32_t)G) << 28));
+    }
+    q.w = __uint_as_float(i);
+    qsorted[pos] = q;
+    ksorted[pos] = keys_in ? keys_in[i] : kKeyInit;
+  }
+}
+
 // ------------------------------------------------------------ brick kernel ---
 // wave-uniform copy of lane l's value (lands in an SGPR)
 __device__ __forceinline__ float readlane_f(float v, int l) {
@@ -677,6 +919,23 @@ static pcd_status run_stencil_stages(pcd_cloud* c, QueryScratch* sc, uint64_t Q,
   return PCD_OK;
 }
 
+static int g_bk_sort = 0;   // 1: force the radix-sort bookkeeping (A/B timing, tests)
+
+// slot table of the cloud for this brick geometry (built on first use, rebuilt when the geometry changes)
+static pcd_status brick_slots(pcd_cloud* c, QueryScratch* sc, const BrickParams& b, hipStream_t s) {
+  const int key[5] = {b.B, b.R, b.S, b.Bx, (int)b.nbricks};
+  if (sc->bk_slot.p && std::memcmp(key, sc->bk_slot_key, sizeof key) == 0) return PCD_OK;
+  PCD_TRY(sc->bk_slot.reserve((size_t)b.nbricks / 32 + 1));
+  DevBuf<uint32_t> flag;
+  PCD_TRY(flag.reserve((size_t)b.nbricks + 1));
+  hipLaunchKernelGGL(k_brick_occupied, dim3(div_up(b.nbricks, 256)), dim3(256), 0, s, c->grid, b, c->cell_start.p, flag.p);
+  hipLaunchKernelGGL(k_brick_bitmap, dim3(div_up(div_up(b.nbricks, 32), 256)), dim3(256), 0, s, flag.p, b.nbricks, sc->bk_slot.p);
+  PCD_HIP_TRY(hipStreamSynchronize(s));   // one-off per cloud and geometry; `flag` goes out of scope
+  sc->bk_nslots = b.nbricks;
+  std::memcpy(sc->bk_slot_key, key, sizeof key);
+  return PCD_OK;
+}
+
 template <int G>
 static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t* d_keys, hipStream_t s, bool refine) {
   const GridParams& g = c->grid;
@@ -690,7 +949,8 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   // fallback list: one slot per query + the chunk slack of every wavefront of the brick kernel (brick_kernel.h)
   // A wavefront leaves a chunk when the next item's unproven queries (<= 8) do not fit: at most 7 of 64 slots stay
   // unused per chunk, so the reserved slots are <= used * 64 / 57 + one chunk per wavefront, used <= Q.
-  const size_t fb_cap = Q + Q / 8 + 8 + (size_t)std::max<unsigned>(256 * g_brick_blocks_per_cu * 4, kStencilBlocks * kStWaves) * kFbChunk;
+  const size_t fb_cap = Q + Q / 8 + 8 + (size_t)std::max<unsigned>(256 * g_brick_blocks_per_cu * 4, kStencilBlocks * kStWaves) * kFbChunk +
+                        (size_t)2048 * 4 * 64;   // + the last chunk of every wavefront of k_bk_emit
   PCD_TRY(sc->fb_list.reserve(fb_cap));   // no memset: every reserved slot is written (a query id or the sentinel)
   PCD_TRY(sc->bk_keys.reserve(2 * Q));
   PCD_TRY(sc->bk_vals.reserve(2 * Q));
@@ -698,19 +958,41 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   PCD_TRY(sc->items.reserve(Q + 1));
   PCD_TRY(sc->counters.reserve(1));
   PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
-  {
+  PCD_TRY(brick_slots(c, sc, b, s));
+  // sort key = brick id: coarse key = id >> shift (at most 4096 buckets), fine key = the low bits (at most 2048)
+  uint32_t shift = 8;
+  while ((((uint64_t)b.nbricks + (1u << shift) - 1) >> shift) > 2304 && shift < 16) ++shift;
+  const uint32_t ncoarse = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)b.nbricks + (1u << shift) - 1) >> shift));
+  if ((1u << shift) <= kBkMaxFine && ncoarse <= kBkMaxCoarse && g_bk_sort == 0) {
+    ScopedKernelTimer t("nn_brick_bookkeeping", s);
+    if (!sc->bk_chist.p) {                 // histogram + cursors: zero once, k_bk_emit leaves them zero
+      PCD_TRY(sc->bk_chist.reserve(4 * (size_t)kBkMaxCoarse + 4));
+      PCD_HIP_TRY(hipMemsetAsync(sc->bk_chist.p, 0, (4 * (size_t)kBkMaxCoarse + 4) * sizeof(uint32_t), s));
+    }
+    uint32_t *chist = sc->bk_chist.p, *cstart = chist + kBkMaxCoarse + 1, *ccur = cstart + kBkMaxCoarse + 1,
+             *bitems = ccur + kBkMaxCoarse + 1;
+    uint32_t *qslot = sc->bk_keys.p, *pslot = sc->bk_keys.p + Q, *pqid = sc->bk_vals.p;
+    const unsigned sblocks = (unsigned)std::min<uint64_t>(div_up(Q, 4096), 256);
+    hipLaunchKernelGGL(k_bk_slots, dim3(sblocks), dim3(1024), 0, s, sc->qf4.p, (uint32_t)Q, g, b, sc->bk_slot.p, shift,
+                       ncoarse, qslot, chist, sc->fb_list.p, sc->counters.p);
+    hipLaunchKernelGGL(k_bk_scatter, dim3(div_up(Q, kBkTileQ)), dim3(1024), 0, s, qslot, (uint32_t)Q, shift, ncoarse, chist,
+                       cstart, ccur, pslot, pqid, sc->counters.p);
+    hipLaunchKernelGGL(k_bk_count<G>, dim3(ncoarse), dim3(256), 0, s, shift, cstart, pslot, bitems);
+    hipLaunchKernelGGL(k_bk_emit<G>, dim3(ncoarse), dim3(256), 0, s, sc->qf4.p, refine ? d_keys : (const uint64_t*)nullptr,
+                       g, b, shift, cstart, pslot, pqid, bitems, chist, ccur, sc->items.p, sc->qsorted.p, sc->ksorted.p,
+                       sc->counters.p);
+  } else {
+    // (grids with more than 8 M occupied bricks: the radix-sort bookkeeping of round 2)
     ScopedKernelTimer t("nn_brick_bookkeeping", s);
     uint32_t *k0 = sc->bk_keys.p, *k1 = sc->bk_keys.p + Q, *v0 = sc->bk_vals.p, *v1 = sc->bk_vals.p + Q;
     hipLaunchKernelGGL(k_brick_keys, dim3(div_up(Q, 256)), dim3(256), 0, s, sc->qf4.p, Q, g, b, k0, v0);
     unsigned end_bit = 1;
     while (end_bit < 32 && ((uint64_t)1 << end_bit) <= (uint64_t)b.nbricks + 1) ++end_bit;
     size_t tb = 0;
-    // rocPRIM's default takes its merge sort (log2(Q / block) launches) up to 2^20 items: Onesweep above 256 k (below that its ~25 us per digit pass cost more than the merge passes)
-// (Onesweep with 10-12-bit digits -- two passes over the 23-bit brick ids instead of three -- does not fit:
-    //  rocPRIM's block ranking then needs 192 KiB - 2 MiB of LDS)
 #ifndef PCD_SORT_MERGE_LIMIT
 #define PCD_SORT_MERGE_LIMIT 262144
 #endif
+    // rocPRIM's default takes its merge sort up to 2^20 items: Onesweep above 256 k
     using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                                rocprim::default_config, PCD_SORT_MERGE_LIMIT>;
     PCD_HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tb, k0, k1, v0, v1, (unsigned)Q, 0u, end_bit, s));
@@ -937,6 +1219,11 @@ pcd_status pcd_nn_set_search(int kernel, int k1, int k2, int k3) {
     for (int i = 0; i < 3; ++i) g_st_k[i] = k[i] > 0 ? k[i] : 0;
   }
   g_nn_kernel = kernel;
+  return PCD_OK;
+}
+
+pcd_status pcd_nn_set_bookkeeping(int radix_sort) {
+  g_bk_sort = radix_sort ? 1 : 0;
   return PCD_OK;
 }
 

@@ -17,6 +17,12 @@ struct QueryScratch {
   DevBuf<uint64_t> keys;       // host-API result keys
   DevBuf<uint32_t> bk_keys, bk_vals;   // (brick id, query id) pairs, unsorted | sorted halves
   DevBuf<uint32_t> bk_item;            // work items per tile of 1024 sorted positions
+  // counting-sort bookkeeping (nn.hip): slot of every brick with a non-empty halo region (kSlotNone otherwise), valid
+  // for the brick geometry in bk_slot_key; per batch the slots' query counters, in-tile prefixes and tile totals
+  DevBuf<uint32_t> bk_slot, bk_chist;   // bk_chist: coarse histogram | bucket starts | bucket cursors
+  DevBuf<uint4> bk_state;               // BkState (nn.hip)
+  int bk_slot_key[5] = {0, 0, 0, 0, 0};
+  uint32_t bk_nslots = 0;
   DevBuf<float4> qsorted;      // brick-sorted query records {x,y,z,bits(query id)}
   DevBuf<uint64_t> ksorted;    // their incoming keys, same order
   DevBuf<uint4> items;         // {first query, brick x, brick y, brick z | count << 28}

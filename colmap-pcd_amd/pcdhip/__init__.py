@@ -523,6 +523,10 @@ def set_nn_search(kernel=1, k1=1, k2=2, k3=0):
     _check(lib().pcd_nn_set_search(int(kernel), int(k1), int(k2), int(k3)))
 
 
+def set_nn_bookkeeping(radix_sort=0):
+    _check(lib().pcd_nn_set_bookkeeping(int(radix_sort)))
+
+
 def set_brick_shift(shift=0):
     _check(lib().pcd_nn_set_brick_shift(int(shift)))
 

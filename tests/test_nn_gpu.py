@@ -342,3 +342,21 @@ def test_brick_then_ball_clipped_stage(gpu, oracle, brs):
         gpu.set_nn_search(0)
         gpu.set_nn_tuning(2, 2, 0)
         gpu.set_brick_shift(0)
+
+
+def test_radix_sort_bookkeeping_still_exact(gpu, oracle):
+    """the round-2 bookkeeping (rocPRIM radix sort of (brick, query) pairs) stays as the path for grids with more than
+    8 M occupied bricks: same keys as the counting-sort bookkeeping and the oracle"""
+    xyz, nrm = synth.cloud_planes(60000, seed=4, patches=10)
+    q = synth.queries(xyz, 9000, seed=5)
+    q[::50] = np.nan
+    q[1::50] += 500.0
+    exp = oracle.nn_bruteforce(xyz, q)
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    try:
+        for radix in (1, 0):
+            gpu.set_nn_bookkeeping(radix)
+            _check_exact(c.nn(q, gpu.NN_GRID), exp, f"bookkeeping radix={radix}")
+    finally:
+        gpu.set_nn_bookkeeping(0)
+    c.close()
