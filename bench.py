@@ -402,6 +402,27 @@ def main():
                                           queries_per_sec=20_000 / t_a)
             ca.close()
 
+    # ---- the Ceres route end to end (shim/ceres_adapter.h): PrepareForEvaluation with Jacobians + one sweep of every
+    # block's Evaluate, PCIe included -- what a colmap user's ceres::Solve sees per evaluation (C++ harness, run as a
+    # child process; config B = Smith Hall 450-like, M = the metric workload) ----
+    if not a.no_extras and rank == 0:
+        import subprocess
+        exe = os.path.join(ROOT, "colmap-pcd_amd", "shim", "ceres_route_bench")
+        if os.path.exists(exe):
+            cr = {}
+            for name, (ni, npt) in (("config_B", (450, 400_000)), ("workload_M", (a.cams, a.points))):
+                try:
+                    r = subprocess.run([exe, str(ni), str(npt), "0"], capture_output=True, timeout=600)
+                    cr[name] = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                except Exception as e:   # noqa: BLE001
+                    cr[name] = {"error": repr(e)}
+            m = cr.get("workload_M", {})
+            extras["ceres_route"] = cr
+            extras["ceres_route_e2e_ms"] = m.get("ceres_route_e2e_ms")
+            extras["ceres_route_def"] = ("HipEvaluation::PrepareForEvaluation(jacobians) [gather + H2D + raw kernels + D2H into the "
+                                         "handle's pinned buffers] + one sweep of CostFunction::Evaluate over every residual "
+                                         "block on the host threads listed; bytes_d2h_jacobians cross PCIe per evaluation")
+
     # ------------------------------------------------- cloud-sharded NN (north_star's collective) ---
     cs = None
     if world > 1 and not a.no_cloud_sharded and hasattr(pdist, "bench_cloud_sharded"):

@@ -723,6 +723,18 @@ __global__ __launch_bounds__(256) void k_ba_lidar_raw(BaDev d, double* __restric
   if (JL) { JL[3 * l] = J[0]; JL[3 * l + 1] = J[1]; JL[3 * l + 2] = J[2]; }
 }
 
+// rows of the variable-pose observations, packed: thread = 16-byte unit of an output row
+template <int N>   // doubles per row
+__global__ void k_pack_rows(const double* __restrict__ in, const uint32_t* __restrict__ vobs, uint64_t nrows,
+                            double* __restrict__ out) {
+  const uint64_t u = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  constexpr int UPR = N / 2;
+  if (u >= nrows * UPR) return;
+  const uint64_t r = u / UPR;
+  const int k = (int)(u - r * UPR);
+  reinterpret_cast<double2*>(out)[u] = reinterpret_cast<const double2*>(in + (size_t)vobs[r] * N)[k];
+}
+
 }  // namespace pcd
 
 using namespace pcd;
@@ -748,6 +760,12 @@ struct pcd_ba {
   DevBuf<double> cost_partial, cost;
   // host-API staging
   DevBuf<double> o_res, o_jq, o_jt, o_jx, o_jl, o_himg, o_gimg, o_hpt, o_gpt, o_w, o_jc, o_hcam, o_gcam, o_ecam, o_wcam;
+  // pcd_ba_evaluate_blocks: rows of the variable-pose observations, packed pose Jacobians, pinned results
+  std::vector<uint32_t> h_pose_row;      // [O] row of observation o in the packed jac_q / jac_t (0xFFFFFFFF: constant pose)
+  uint64_t n_pose_rows = 0;
+  DevBuf<uint32_t> vobs;                 // [n_pose_rows] observation of every packed row
+  DevBuf<double> p_jq, p_jt;             // packed pose Jacobians (only when some pose is constant)
+  PinnedBuf<double> h_blocks;            // residuals | jac_q | jac_t | jac_X | jac_lidar | jac_cam
   BaDev dev() const {
     BaDev d;
     d.cam_model = cam_model.p; d.cam_off = cam_off.p; d.cam_params = cam_params.p;
@@ -972,6 +990,21 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
     }
   }
 #undef UP
+  {  // rows of the packed pose Jacobians (pcd_ba_evaluate_blocks)
+    b->h_pose_row.assign(b->O, 0xFFFFFFFFu);
+    std::vector<uint32_t> vobs;
+    vobs.reserve(b->O);
+    for (uint64_t o = 0; o < b->O; ++o)
+      if (!(d->image_const_pose && d->image_const_pose[d->obs_image[o]])) {
+        b->h_pose_row[o] = (uint32_t)vobs.size();
+        vobs.push_back((uint32_t)o);
+      }
+    b->n_pose_rows = vobs.size();
+    if (b->n_pose_rows != b->O) {
+      pcd_status sv = upload(b->vobs, vobs.data(), vobs.size());
+      if (sv != PCD_OK) return fail(sv);
+    }
+  }
   // one partial per workgroup of whichever of the two cost-producing kernels has the larger grid (cost_blocks)
   pcd_status s1 = b->cost_partial.reserve((size_t)std::max(cost_blocks(b, true), cost_blocks(b, false)) + 1);
   if (s1 != PCD_OK) return fail(s1);
@@ -1096,6 +1129,54 @@ pcd_status pcd_ba_observation_errors(pcd_ba* b, double* sq_err, double* depth) {
   PCD_TRY(pcd_ba_observation_errors_device(b, sq_err ? b->o_jq.p : nullptr, depth ? b->o_jt.p : nullptr, nullptr));
   if (sq_err) PCD_HIP_TRY(hipMemcpy(sq_err, b->o_jq.p, b->O * sizeof(double), hipMemcpyDeviceToHost));
   if (depth) PCD_HIP_TRY(hipMemcpy(depth, b->o_jt.p, b->O * sizeof(double), hipMemcpyDeviceToHost));
+  return PCD_OK;
+}
+
+pcd_status pcd_ba_evaluate_blocks(pcd_ba* b, int want_jacobians, int want_jac_cam, pcd_ba_blocks* out) {
+  PCD_REQUIRE(b && out, "null pointer");
+  PCD_HIP_TRY(hipSetDevice(b->device));
+  std::memset(out, 0, sizeof *out);
+  const uint64_t O = b->O, L = b->L, V = b->n_pose_rows;
+  const bool packed = V != O;
+  const size_t n_res = 2 * O + L, n_jq = want_jacobians ? 8 * V : 0, n_jt = want_jacobians ? 6 * V : 0,
+               n_jx = want_jacobians ? 6 * O : 0, n_jl = want_jacobians ? 3 * L : 0,
+               n_jc = (want_jacobians && want_jac_cam) ? 2 * (size_t)PCD_CAM_JAC_STRIDE * O : 0;
+  PCD_TRY(b->h_blocks.reserve(n_res + n_jq + n_jt + n_jx + n_jl + n_jc + 2));
+  PCD_TRY(b->o_res.reserve(std::max<size_t>(n_res, 1)));
+  pcd_ba_out d{};
+  d.residuals = b->o_res.p;
+  if (want_jacobians) {
+    PCD_TRY(b->o_jq.reserve(std::max<size_t>(8 * O, 1))); PCD_TRY(b->o_jt.reserve(std::max<size_t>(6 * O, 1)));
+    PCD_TRY(b->o_jx.reserve(std::max<size_t>(6 * O, 1))); PCD_TRY(b->o_jl.reserve(std::max<size_t>(3 * L, 1)));
+    d.jac_q = b->o_jq.p; d.jac_t = b->o_jt.p; d.jac_X = b->o_jx.p; d.jac_lidar = b->o_jl.p;
+    if (n_jc) { PCD_TRY(b->o_jc.reserve(n_jc)); d.jac_cam = b->o_jc.p; }
+    if (packed) { PCD_TRY(b->p_jq.reserve(std::max<size_t>(8 * V, 1))); PCD_TRY(b->p_jt.reserve(std::max<size_t>(6 * V, 1))); }
+  }
+  hipStream_t s = nullptr;
+  PCD_TRY(pcd_ba_evaluate_device(b, &d, s));
+  const double *src_jq = b->o_jq.p, *src_jt = b->o_jt.p;
+  if (want_jacobians && packed && V) {
+    hipLaunchKernelGGL(k_pack_rows<8>, dim3(div_up(V * 4, 256)), dim3(256), 0, s, b->o_jq.p, b->vobs.p, V, b->p_jq.p);
+    hipLaunchKernelGGL(k_pack_rows<6>, dim3(div_up(V * 3, 256)), dim3(256), 0, s, b->o_jt.p, b->vobs.p, V, b->p_jt.p);
+    src_jq = b->p_jq.p; src_jt = b->p_jt.p;
+  }
+  double* h = b->h_blocks.p;
+  auto down = [&](const double*& slot, const double* src, size_t n) -> hipError_t {
+    slot = n ? h : nullptr;
+    const hipError_t e = n ? hipMemcpyAsync(h, src, n * sizeof(double), hipMemcpyDeviceToHost, s) : hipSuccess;
+    h += n;
+    out->bytes_d2h += n * sizeof(double);
+    return e;
+  };
+  PCD_HIP_TRY(down(out->residuals, b->o_res.p, n_res));
+  PCD_HIP_TRY(down(out->jac_q, src_jq, n_jq));
+  PCD_HIP_TRY(down(out->jac_t, src_jt, n_jt));
+  PCD_HIP_TRY(down(out->jac_X, b->o_jx.p, n_jx));
+  PCD_HIP_TRY(down(out->jac_lidar, b->o_jl.p, n_jl));
+  PCD_HIP_TRY(down(out->jac_cam, b->o_jc.p, n_jc));
+  PCD_HIP_TRY(hipStreamSynchronize(s));
+  out->pose_row = b->h_pose_row.data();
+  out->num_pose_rows = V;
   return PCD_OK;
 }
 

@@ -57,8 +57,8 @@ struct ShimParameterSource {
   double* Params(camera_t id) const { return rec->cameras.at(id).params.data(); }
 };
 
-struct HipBlockBuffers {   // results of the last PrepareForEvaluation, read by every block
-  std::vector<double> residuals, jac_q, jac_t, jac_X, jac_lidar, jac_cam;
+struct HipBlockBuffers {   // results of the last PrepareForEvaluation, read by every block: views of the pinned host
+  pcd_ba_blocks b{};       // buffers the pcd_ba handle owns (pcd_ba_evaluate_blocks)
   bool have_jacobians = false;
 };
 
@@ -73,22 +73,26 @@ class HipReprojectionBlock : public ceres::CostFunction {
     mutable_parameter_block_sizes()->push_back(K_);
   }
   bool Evaluate(double const* const*, double* residuals, double** jacobians) const override {
-    residuals[0] = buf_->residuals[2 * o_];
-    residuals[1] = buf_->residuals[2 * o_ + 1];
+    const pcd_ba_blocks& r = buf_->b;
+    residuals[0] = r.residuals[2 * o_];
+    residuals[1] = r.residuals[2 * o_ + 1];
     if (!jacobians) return true;
     if (!buf_->have_jacobians) return false;   // Ceres asked for Jacobians the callback was not told to prepare
     int b = 0;
     if (!cpose_) {
-      if (jacobians[b]) std::memcpy(jacobians[b], &buf_->jac_q[8 * o_], 8 * sizeof(double));
+      const size_t row = r.pose_row[o_];       // constant-pose blocks have no pose rows (and no pose parameter blocks)
+      if (jacobians[b]) std::memcpy(jacobians[b], r.jac_q + 8 * row, 8 * sizeof(double));
       ++b;
-      if (jacobians[b]) std::memcpy(jacobians[b], &buf_->jac_t[6 * o_], 6 * sizeof(double));
+      if (jacobians[b]) std::memcpy(jacobians[b], r.jac_t + 6 * row, 6 * sizeof(double));
       ++b;
     }
-    if (jacobians[b]) std::memcpy(jacobians[b], &buf_->jac_X[6 * o_], 6 * sizeof(double));
+    if (jacobians[b]) std::memcpy(jacobians[b], r.jac_X + 6 * o_, 6 * sizeof(double));
     ++b;
-    if (jacobians[b])
-      for (int r = 0; r < 2; ++r)   // device rows have PCD_CAM_JAC_STRIDE columns, Ceres wants 2 x K row-major
-        std::memcpy(jacobians[b] + r * K_, &buf_->jac_cam[(2 * o_ + r) * PCD_CAM_JAC_STRIDE], K_ * sizeof(double));
+    if (jacobians[b]) {
+      if (!r.jac_cam) return false;
+      for (int k = 0; k < 2; ++k)   // device rows have PCD_CAM_JAC_STRIDE columns, Ceres wants 2 x K row-major
+        std::memcpy(jacobians[b] + k * K_, r.jac_cam + (2 * o_ + k) * PCD_CAM_JAC_STRIDE, K_ * sizeof(double));
+    }
     return true;
   }
 
@@ -107,10 +111,10 @@ class HipLidarBlock : public ceres::CostFunction {
     mutable_parameter_block_sizes()->push_back(3);
   }
   bool Evaluate(double const* const*, double* residuals, double** jacobians) const override {
-    residuals[0] = buf_->residuals[2 * O_ + l_];
+    residuals[0] = buf_->b.residuals[2 * O_ + l_];
     if (jacobians && jacobians[0]) {
       if (!buf_->have_jacobians) return false;
-      std::memcpy(jacobians[0], &buf_->jac_lidar[3 * l_], 3 * sizeof(double));
+      std::memcpy(jacobians[0], buf_->b.jac_lidar + 3 * l_, 3 * sizeof(double));
     }
     return true;
   }
@@ -125,11 +129,6 @@ class HipEvaluation : public ceres::EvaluationCallback {
  public:
   // `ba` must have been SetUp() and Create()d; `src` gives the parameter memory Ceres optimises in place
   HipEvaluation(BundleAdjusterHip* ba, const Source& src) : ba_(ba), src_(src) {
-    const size_t O = ba_->obs_image_.size(), L = ba_->lidar_point_.size();
-    buf_.residuals.assign(2 * O + L, 0.0);
-    buf_.jac_q.assign(8 * O, 0.0); buf_.jac_t.assign(6 * O, 0.0); buf_.jac_X.assign(6 * O, 0.0);
-    buf_.jac_lidar.assign(3 * L, 0.0);
-    buf_.jac_cam.assign(2 * (size_t)PCD_CAM_JAC_STRIDE * O, 0.0);
     for (uint8_t v : ba_->cam_refine_) cameras_variable_ |= v != 0;
   }
 
@@ -151,14 +150,10 @@ class HipEvaluation : public ceres::EvaluationCallback {
         ok_ &= pcd_ba_set_camera_parameters(ba_->handle(), ba_->cam_params_.data()) == PCD_OK;
       }
     }
-    pcd_ba_out o{};
-    o.residuals = buf_.residuals.data();
-    if (evaluate_jacobians) {
-      o.jac_q = buf_.jac_q.data(); o.jac_t = buf_.jac_t.data(); o.jac_X = buf_.jac_X.data();
-      o.jac_lidar = buf_.jac_lidar.data();
-      if (cameras_variable_) o.jac_cam = buf_.jac_cam.data();   // constant cameras: Ceres passes NULL for that block
-    }
-    ok_ &= pcd_ba_evaluate(ba_->handle(), &o) == PCD_OK;        // ONE batch for every residual block
+    // ONE batch for every residual block; results in pinned memory of the handle (constant cameras: Ceres passes
+    // NULL for the camera block, so its Jacobian is not even computed)
+    ok_ &= pcd_ba_evaluate_blocks(ba_->handle(), evaluate_jacobians ? 1 : 0, cameras_variable_ ? 1 : 0, &buf_.b) == PCD_OK;
+    bytes_d2h_ += buf_.b.bytes_d2h;
     buf_.have_jacobians = evaluate_jacobians && ok_;
     ++num_evaluations_;
   }
@@ -174,6 +169,7 @@ class HipEvaluation : public ceres::EvaluationCallback {
 
   bool ok() const { return ok_; }
   size_t num_evaluations() const { return num_evaluations_; }
+  uint64_t bytes_d2h() const { return bytes_d2h_; }
   const HipBlockBuffers& buffers() const { return buf_; }
 
  private:
@@ -182,6 +178,7 @@ class HipEvaluation : public ceres::EvaluationCallback {
   HipBlockBuffers buf_;
   bool cameras_variable_ = false, ok_ = true;
   size_t num_evaluations_ = 0;
+  uint64_t bytes_d2h_ = 0;
 };
 
 }  // namespace colmap_hip

@@ -457,7 +457,8 @@ static int TestGpuProjection() {
 // (optim/bundle_adjustment.cc:858-893, :967-983, :1031-1037); no GPU needed
 static void TestCeresBlockShapes() {
   HipBlockBuffers buf;
-  buf.residuals = {1, 2, 3, 4, 5};
+  static const double res5[5] = {1, 2, 3, 4, 5};
+  buf.b.residuals = res5;
   HipReprojectionBlock var(&buf, 0, false, 4), cst(&buf, 1, true, 8);
   HipLidarBlock lid(&buf, 2, 0);
   CHECK_EQ(var.num_residuals(), 2); CHECK_EQ(cst.num_residuals(), 2); CHECK_EQ(lid.num_residuals(), 1);

@@ -401,6 +401,26 @@ typedef struct {
 } pcd_ba_out;
 
 pcd_status pcd_ba_evaluate(pcd_ba* ba, const pcd_ba_out* out);                 /* host outputs   */
+
+/* The Ceres route (optim/bundle_adjustment.cc:858-893, :967-983, :1031-1037: every residual block's Evaluate copies
+ * its rows): the raw blocks of ALL residual blocks land in PINNED host buffers owned by the handle -- one device pass,
+ * then one asynchronous copy per array at the pinned PCIe rate instead of pcd_ba_evaluate's synchronous copies into
+ * the caller's pageable memory.  Constant-pose blocks (the reference's BundleAdjustmentConstantPoseCostFunction has
+ * no pose parameter blocks) carry no pose Jacobians: jac_q / jac_t hold one row per VARIABLE-pose observation, packed
+ * on the device, and pose_row[o] is observation o's row (0xFFFFFFFF: none).  The pointers stay valid until the next
+ * pcd_ba_evaluate_blocks / pcd_ba_destroy on the handle. */
+typedef struct {
+  const double* residuals;   /* [2*O + L]                                                       */
+  const double* jac_q;       /* [num_pose_rows][2][4]   NULL when want_jacobians == 0           */
+  const double* jac_t;       /* [num_pose_rows][2][3]                                           */
+  const double* jac_X;       /* [O][2][3]                                                       */
+  const double* jac_lidar;   /* [L][3]                                                          */
+  const double* jac_cam;     /* [O][2][PCD_CAM_JAC_STRIDE] or NULL (want_jac_cam == 0)          */
+  const uint32_t* pose_row;  /* [O] host array (fixed at pcd_ba_create)                         */
+  uint64_t num_pose_rows;
+  uint64_t bytes_d2h;        /* bytes that crossed PCIe device -> host in this call             */
+} pcd_ba_blocks;
+pcd_status pcd_ba_evaluate_blocks(pcd_ba* ba, int want_jacobians, int want_jac_cam, pcd_ba_blocks* out);
 pcd_status pcd_ba_evaluate_device(pcd_ba* ba, const pcd_ba_out* d_out, void* stream);  /* device outputs */
 /* Inputs of the post-BA filters, per observation (either pointer may be NULL):
  *   sq_err[o] = CalculateSquaredReprojectionError (base/projection.cc:104-117), DBL_MAX when the point is not
