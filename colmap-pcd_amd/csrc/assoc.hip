@@ -66,8 +66,8 @@ __device__ __forceinline__ void assoc_core(const double X[3], const float p[3], 
   if (o.dist2plane) o.dist2plane[i] = d2p;
 }
 
-__global__ void k_associate(const float4* __restrict__ pts4, const float4* __restrict__ nrm4, uint64_t n,
-                            uint32_t index_base, uint32_t index_stride, const double* __restrict__ q, uint64_t Q,
+__global__ void k_associate(const float4* __restrict__ pts4, const float4* __restrict__ nrm4, ShardIndex si,
+                            const double* __restrict__ q, uint64_t Q,
                             const uint64_t* __restrict__ keys, const double* __restrict__ max_range,
                             uint64_t mr_count, int mode, AssocOut o) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -79,8 +79,8 @@ __global__ void k_associate(const float4* __restrict__ pts4, const float4* __res
   if (found) {
     // same ownership test as k_winner_payload: a key another shard won (e.g. after a cross-rank MIN)
     // must not be mapped onto one of this shard's rows
-    const uint64_t li = (uint64_t)(gi - index_base) / index_stride;
-    if (gi >= index_base && (gi - index_base) % index_stride == 0 && li < n) {
+    const uint64_t li = shard_local_row(si, gi);
+    if (li != ~0ull) {
       const float4 a = pts4[li], b = nrm4[li];
       p[0] = a.x; p[1] = a.y; p[2] = a.z;
       nv[0] = b.x; nv[1] = b.y; nv[2] = b.z;
@@ -96,22 +96,18 @@ __global__ void k_associate(const float4* __restrict__ pts4, const float4* __res
 }
 
 // winner (xyz, normal) of the keys this shard owns, as int32 bit patterns; zeros elsewhere
-__global__ void k_winner_payload(const float4* __restrict__ pts4, const float4* __restrict__ nrm4, uint64_t n,
-                                 uint32_t index_base, uint32_t index_stride, const uint64_t* __restrict__ keys,
-                                 uint64_t Q, int32_t* __restrict__ payload) {
+__global__ void k_winner_payload(const float4* __restrict__ pts4, const float4* __restrict__ nrm4, ShardIndex si,
+                                 const uint64_t* __restrict__ keys, uint64_t Q, int32_t* __restrict__ payload) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= Q) return;
   const uint64_t key = keys[i];
   int32_t out[6] = {0, 0, 0, 0, 0, 0};
   if (key != PCD_KEY_NONE) {
-    const uint32_t gi = (uint32_t)key;
-    if (gi >= index_base && (gi - index_base) % index_stride == 0) {
-      const uint64_t li = (uint64_t)(gi - index_base) / index_stride;
-      if (li < n) {
-        const float4 a = pts4[li], b = nrm4[li];
-        out[0] = __float_as_int(a.x); out[1] = __float_as_int(a.y); out[2] = __float_as_int(a.z);
-        out[3] = __float_as_int(b.x); out[4] = __float_as_int(b.y); out[5] = __float_as_int(b.z);
-      }
+    const uint64_t li = shard_local_row(si, (uint32_t)key);
+    if (li != ~0ull) {
+      const float4 a = pts4[li], b = nrm4[li];
+      out[0] = __float_as_int(a.x); out[1] = __float_as_int(a.y); out[2] = __float_as_int(a.z);
+      out[3] = __float_as_int(b.x); out[4] = __float_as_int(b.y); out[5] = __float_as_int(b.z);
     }
   }
   for (int k = 0; k < 6; ++k) payload[6 * i + k] = out[k];
@@ -220,8 +216,8 @@ pcd_status pcd_associate_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q,
   }
   {
     ScopedKernelTimer t("associate", s);
-    hipLaunchKernelGGL(k_associate, dim3(div_up(Q, 256)), dim3(256), 0, s, c->pts4.p, c->nrm4.p, c->n, c->index_base,
-                       c->index_stride, d_q_xyz, Q, keys, gate_mode == PCD_GATE_CONTROLLER ? nullptr : d_max_range,
+    hipLaunchKernelGGL(k_associate, dim3(div_up(Q, 256)), dim3(256), 0, s, c->pts4.p, c->nrm4.p, c->shard_index(),
+                       d_q_xyz, Q, keys, gate_mode == PCD_GATE_CONTROLLER ? nullptr : d_max_range,
                        max_range_count, gate_mode, to_dev(d_out));
   }
   PCD_HIP_TRY(hipGetLastError());
@@ -235,8 +231,8 @@ pcd_status pcd_nn_winner_payload_device(pcd_cloud* c, const uint64_t* d_keys, ui
   PCD_HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
   ScopedKernelTimer t("winner_payload", s);
-  hipLaunchKernelGGL(k_winner_payload, dim3(div_up(Q, 256)), dim3(256), 0, s, c->pts4.p, c->nrm4.p, c->n,
-                     c->index_base, c->index_stride, d_keys, Q, d_payload);
+  hipLaunchKernelGGL(k_winner_payload, dim3(div_up(Q, 256)), dim3(256), 0, s, c->pts4.p, c->nrm4.p, c->shard_index(),
+                     d_keys, Q, d_payload);
   PCD_HIP_TRY(hipGetLastError());
   return PCD_OK;
 }

@@ -42,6 +42,23 @@ struct PyramidParams {
 
 struct QueryScratch;  // nn.hip
 
+// ownership of a global index by a shard: local row or 0xFFFFFFFFFFFFFFFF
+struct ShardIndex {
+  uint32_t base, stride;
+  uint64_t n;
+  const uint32_t* g2l;   // NULL: base / stride arithmetic
+  uint64_t g2l_n;
+};
+__device__ __forceinline__ uint64_t shard_local_row(const ShardIndex& si, uint32_t gi) {
+  if (si.g2l) {
+    const uint32_t l = gi < si.g2l_n ? si.g2l[gi] : 0xFFFFFFFFu;
+    return l == 0xFFFFFFFFu ? ~0ull : (uint64_t)l;
+  }
+  if (gi < si.base || (gi - si.base) % si.stride != 0) return ~0ull;
+  const uint64_t li = (uint64_t)(gi - si.base) / si.stride;
+  return li < si.n ? li : ~0ull;
+}
+
 }  // namespace pcd
 
 struct pcd_cloud {
@@ -49,6 +66,10 @@ struct pcd_cloud {
   uint64_t n = 0;  // rows kept
   uint64_t m = 0;  // finite rows indexed in the grid
   uint32_t index_base = 0, index_stride = 1;
+  // shards with an arbitrary row -> global index map (pcd_cloud_create_sharded): global index of local row i, and the
+  // inverse over the whole cloud (0xFFFFFFFF = not a row of this shard).  Empty: global = index_base + i * index_stride.
+  pcd::DevBuf<uint32_t> row_index, g2l;
+  uint64_t g2l_n = 0;
   pcd::DevBuf<float4> pts4, nrm4, sorted;
   pcd::DevBuf<uint32_t> cell_start;
   pcd::DevBuf<float> blk_aabb, sub_aabb;
@@ -58,4 +79,12 @@ struct pcd_cloud {
   float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};   // tight bounds of the finite rows (valid when m > 0)
   double build_ms = 0;
   pcd::QueryScratch* scratch = nullptr;
+  pcd::ShardIndex shard_index() const { return pcd::ShardIndex{index_base, index_stride, n, g2l.p, g2l_n}; }
 };
+
+namespace pcd {
+// pcd_cloud_create with an explicit global index per row (row_index[n], host; NULL = index_base / index_stride) over
+// a cloud of global_n rows in total
+pcd_status cloud_create_indexed(const float* xyz, const float* nrm, uint64_t n, const pcd_cloud_options* opts,
+                                const uint32_t* row_index, uint64_t global_n, pcd_cloud** out);
+}

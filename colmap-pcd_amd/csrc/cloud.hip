@@ -125,7 +125,8 @@ __global__ void k_cell_keys(const float4* __restrict__ pts4, uint64_t n, GridPar
 }
 
 __global__ void k_gather_sorted(const float4* __restrict__ pts4, const uint32_t* __restrict__ order, uint64_t m,
-                                uint32_t index_base, uint32_t index_stride, float4* __restrict__ sorted) {
+                                uint32_t index_base, uint32_t index_stride, const uint32_t* __restrict__ row_index,
+                                float4* __restrict__ sorted) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= m + kSortedSpare) return;
   // rows m .. m+15 repeat the last record: the brick kernel reads ranges in groups of 4 records and may run up to
@@ -133,7 +134,7 @@ __global__ void k_gather_sorted(const float4* __restrict__ pts4, const uint32_t*
   // (stencil_kernel.h); a repeated real point cannot change a minimum
   uint32_t src = order[i < m ? i : m - 1];
   float4 p = pts4[src];
-  p.w = __uint_as_float(index_base + src * index_stride);
+  p.w = __uint_as_float(row_index ? row_index[src] : index_base + src * index_stride);
   sorted[i] = p;
 }
 
@@ -368,7 +369,7 @@ static pcd_status build_grid(pcd_cloud* c, float user_h, hipStream_t s) {
     PCD_HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, k0.p, k1.p, v0.p, v1.p, n, 0, 32, s));
     if (c->m)
       hipLaunchKernelGGL(k_gather_sorted, dim3(div_up(c->m + kSortedSpare, 256)), dim3(256), 0, s, c->pts4.p, v1.p, c->m,
-                         c->index_base, c->index_stride, c->sorted.p);
+                         c->index_base, c->index_stride, c->row_index.p, c->sorted.p);
     PCD_HIP_TRY(hipStreamSynchronize(s));
   }
 
@@ -423,6 +424,18 @@ void pcd_cloud_options_default(pcd_cloud_options* o) {
 
 pcd_status pcd_cloud_create(const float* xyz, const float* nrm, uint64_t n, const pcd_cloud_options* opts,
                             pcd_cloud** out) {
+  return pcd::cloud_create_indexed(xyz, nrm, n, opts, nullptr, 0, out);
+}
+
+}  // extern "C"
+
+__global__ static void k_fill_g2l(const uint32_t* __restrict__ row_index, uint64_t n, uint32_t* __restrict__ g2l) {
+  const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i < n) g2l[row_index[i]] = (uint32_t)i;
+}
+
+pcd_status pcd::cloud_create_indexed(const float* xyz, const float* nrm, uint64_t n, const pcd_cloud_options* opts,
+                                     const uint32_t* row_index, uint64_t global_n, pcd_cloud** out) {
   PCD_REQUIRE(out, "out is null");
   *out = nullptr;
   pcd_cloud_options o;
@@ -444,6 +457,16 @@ pcd_status pcd_cloud_create(const float* xyz, const float* nrm, uint64_t n, cons
   c->index_stride = o.index_stride;
   hipStream_t s = nullptr;
   auto fail = [&](pcd_status st) { pcd_cloud_destroy(c); return st; };
+  if (row_index) {
+    if (o.raw_lidar_frame) { set_error("indexed shards need raw_lidar_frame = 0"); return fail(PCD_ERR_INVALID); }
+    pcd_status sr;
+    if ((sr = c->row_index.reserve(std::max<uint64_t>(n, 1))) != PCD_OK) return fail(sr);
+    if ((sr = c->g2l.reserve(std::max<uint64_t>(global_n, 1))) != PCD_OK) return fail(sr);
+    c->g2l_n = global_n;
+    if (n && hipMemcpy(c->row_index.p, row_index, n * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return fail(PCD_ERR_HIP);
+    if (hipMemset(c->g2l.p, 0xFF, std::max<uint64_t>(global_n, 1) * sizeof(uint32_t)) != hipSuccess) return fail(PCD_ERR_HIP);
+    if (n) hipLaunchKernelGGL(k_fill_g2l, dim3(div_up(n, 256)), dim3(256), 0, s, c->row_index.p, n, c->g2l.p);
+  }
 
   const size_t row = o.layout == PCD_LAYOUT_AOS32 ? 8 : 3;
   DevBuf<float> d_xyz, d_nrm;
@@ -485,6 +508,8 @@ pcd_status pcd_cloud_create(const float* xyz, const float* nrm, uint64_t n, cons
   *out = c;
   return PCD_OK;
 }
+
+extern "C" {
 
 void pcd_cloud_destroy(pcd_cloud* c) {
   if (!c) return;

@@ -177,6 +177,7 @@ __global__ void k_unpack_keys(const uint64_t* __restrict__ keys, uint64_t Q, uin
 // (broadcast reads), chunks are combined with atomicMin on the packed key.
 __global__ __launch_bounds__(256) void k_nn_bruteforce(const float4* __restrict__ pts4, uint64_t n,
                                                         uint32_t index_base, uint32_t index_stride,
+                                                        const uint32_t* __restrict__ row_index,
                                                         const float4* __restrict__ qf4, uint64_t Q,
                                                         uint64_t chunk, uint64_t* __restrict__ keys) {
   __shared__ float4 tile[1024];
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void k_nn_bruteforce(const float4* __restrict_
     __syncthreads();
     for (int j = threadIdx.x; j < tn; j += 256) {
       float4 p = pts4[t0 + j];
-      p.w = __uint_as_float(index_base + (uint32_t)(t0 + j) * index_stride);
+      p.w = __uint_as_float(row_index ? row_index[t0 + j] : index_base + (uint32_t)(t0 + j) * index_stride);
       tile[j] = p;
     }
     __syncthreads();
@@ -1098,7 +1099,7 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
       const uint64_t chunk = ((c->n + chunks - 1) / chunks + 1023) / 1024 * 1024;
       chunks = div_up(c->n, chunk);
       hipLaunchKernelGGL(k_nn_bruteforce, dim3(qblocks, chunks), dim3(256), 0, s, c->pts4.p, c->n, c->index_base,
-                         c->index_stride, sc->qf4.p, Q, chunk, d_keys);
+                         c->index_stride, c->row_index.p, sc->qf4.p, Q, chunk, d_keys);
     } else if (algo == PCD_NN_FALLBACK_ONLY || (algo == PCD_NN_AUTO && Q <= kSmallBatch)) {
       // (refining another shard's keys: the keys come in, so the prepare / finalize kernels stay)
       PCD_TRY(sc->counters.reserve(1));

@@ -110,6 +110,9 @@ ABI_SYMBOLS = [
     "pcd_proj_last_pairs", "pcd_proj_scale_coeffs", "pcd_proj_set_new_images",
     "pcd_sift_matcher_create", "pcd_sift_matcher_destroy", "pcd_sift_matcher_set_max_sift",
     "pcd_sift_matcher_set_descriptors", "pcd_sift_matcher_match",
+    "pcd_ba_evaluate_blocks",
+    "pcd_cloud_create_sharded", "pcd_cloud_shards_destroy", "pcd_cloud_shards_count", "pcd_cloud_shards_size",
+    "pcd_cloud_shards_get", "pcd_nn_query_sharded", "pcd_associate_sharded",
 ]
 
 
@@ -337,6 +340,70 @@ def associate_from_payload_device(device, d_q, Q, d_max_range, mr_count, gate_mo
                                                   "nn_idx", "nn_sqdist")])
     _check(lib().pcd_associate_from_payload_device(device, _ptr(d_q), Q, _ptr(d_max_range), mr_count, gate_mode,
                                                    _ptr(d_keys), _ptr(d_payload), C.byref(ao), C.c_void_p(stream)))
+
+
+class ShardReduce(C.Structure):
+    """pcd_shard_reduce: the exchange steps of the sharded search (NULL members: the library's own peer-copy reduction)"""
+    MINFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_uint64)
+    SUMFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_uint64)
+    _fields_ = [("min_u64", MINFN), ("sum_i32", SUMFN), ("user", C.c_void_p)]
+
+
+class ShardedCloud:
+    """One cloud over several devices of this process (pcd_cloud_create_sharded): what a multi-GPU C++ host builds in
+    LoadPointcloud.  devices may repeat (tests put every shard on device 0)."""
+
+    def __init__(self, xyz, nrm, devices, raw_lidar_frame=True, cell_size=0.0):
+        L = lib()
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        nrm = np.ascontiguousarray(nrm, np.float32)
+        o = CloudOptions()
+        L.pcd_cloud_options_default(C.byref(o))
+        o.raw_lidar_frame = int(raw_lidar_frame)
+        o.cell_size = cell_size
+        dv = (C.c_int * len(devices))(*devices)
+        L.pcd_cloud_create_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(CloudOptions), C.POINTER(C.c_int),
+                                               C.c_int, C.POINTER(C.c_void_p)]
+        L.pcd_cloud_shards_destroy.argtypes = [C.c_void_p]
+        L.pcd_cloud_shards_destroy.restype = None
+        L.pcd_cloud_shards_size.argtypes = [C.c_void_p]
+        L.pcd_cloud_shards_size.restype = C.c_uint64
+        self._h = C.c_void_p()
+        n = xyz.shape[0]
+        _check(L.pcd_cloud_create_sharded(_vp(xyz) if n else None, _vp(nrm) if n else None, n, C.byref(o), dv, len(devices),
+                                          C.byref(self._h)))
+
+    def __len__(self):
+        return int(lib().pcd_cloud_shards_size(self._h))
+
+    def close(self):
+        if self._h:
+            lib().pcd_cloud_shards_destroy(self._h)
+            self._h = None
+
+    def nn(self, q, reduce=None):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        Q = q.shape[0]
+        idx = np.empty(Q, np.uint32); sq = np.empty(Q, np.float32); found = np.empty(Q, np.uint8)
+        L = lib()
+        L.pcd_nn_query_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.pcd_nn_query_sharded(self._h, _vp(q) if Q else None, Q, C.byref(reduce) if reduce is not None else None,
+                                      _vp(idx), _vp(sq), _vp(found)))
+        return idx, sq, found
+
+    def associate(self, q, max_range, gate_mode=0, reduce=None):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, 3)
+        Q = q.shape[0]
+        mr = np.ascontiguousarray(np.atleast_1d(max_range), np.float64)
+        out = dict(lidar_xyz=np.zeros((Q, 3)), abcd=np.zeros((Q, 4)), type=np.zeros(Q, np.uint8), dist=np.zeros(Q),
+                   angle=np.zeros(Q), dist2plane=np.zeros(Q), nn_idx=np.zeros(Q, np.uint32), nn_sqdist=np.zeros(Q, np.float32))
+        ao = AssocOut(*[_vp(out[k]) for k in ("lidar_xyz", "abcd", "type", "dist", "angle", "dist2plane", "nn_idx", "nn_sqdist")])
+        L = lib()
+        L.pcd_associate_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
+                                            C.POINTER(AssocOut)]
+        _check(L.pcd_associate_sharded(self._h, _vp(q), Q, _vp(mr), mr.shape[0], gate_mode,
+                                       C.byref(reduce) if reduce is not None else None, C.byref(ao)))
+        return out
 
 
 def sift_match(d1, d2, max_ratio=0.8, max_distance=0.7, cross_check=True, device=0):

@@ -10,6 +10,8 @@
 #include <cstring>
 #include <random>
 
+#include <hip/hip_runtime_api.h>   // the sharded-cloud test's caller-side reduction moves device buffers
+
 #include "ba_problem.h"
 #include "ceres_adapter.h"
 #include "pose_reader.h"
@@ -623,6 +625,94 @@ static int TestGpuCeresAdapterEndToEnd() {
   return 0;
 }
 
+// ---- one cloud over several shards of this process (include/pcdhip.h "One cloud over several devices") ------------
+// the exchange steps as a caller-supplied reduction: device -> host, reduce, host -> device (a production host would
+// call RCCL here); every shard sits on device 0 on this box
+static int HostMinU64(void*, uint64_t* const* buf, const int* devices, int n, uint64_t count) {
+  std::vector<uint64_t> acc(count), tmp(count);
+  for (int s = 0; s < n; ++s) {
+    if (hipSetDevice(devices[s]) != hipSuccess) return 1;
+    if (hipMemcpy(s ? tmp.data() : acc.data(), buf[s], count * 8, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    if (s) for (uint64_t i = 0; i < count; ++i) acc[i] = std::min(acc[i], tmp[i]);
+  }
+  for (int s = 0; s < n; ++s) {
+    if (hipSetDevice(devices[s]) != hipSuccess) return 1;
+    if (hipMemcpy(buf[s], acc.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
+  }
+  return 0;
+}
+static int HostSumI32(void*, int32_t* const* buf, const int* devices, int n, uint64_t count) {
+  std::vector<int32_t> acc(count), tmp(count);
+  for (int s = 0; s < n; ++s) {
+    if (hipSetDevice(devices[s]) != hipSuccess) return 1;
+    if (hipMemcpy(s ? tmp.data() : acc.data(), buf[s], count * 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    if (s) for (uint64_t i = 0; i < count; ++i) acc[i] += tmp[i];
+  }
+  for (int s = 0; s < n; ++s) {
+    if (hipSetDevice(devices[s]) != hipSuccess) return 1;
+    if (hipMemcpy(buf[s], acc.data(), count * 4, hipMemcpyHostToDevice) != hipSuccess) return 1;
+  }
+  return 0;
+}
+
+static int TestGpuShardedCloud() {
+  // planar patches + exact duplicates far apart in file order (ties across shard cuts go to the lowest original index)
+  std::mt19937 rng(5);
+  std::uniform_real_distribution<float> u(0.f, 1.f);
+  std::normal_distribution<double> g(0.0, 0.25);
+  const size_t n = 40000, Q = 6000;
+  std::vector<float> xyz(3 * n), nrm(3 * n);
+  for (size_t i = 0; i < n; ++i) {
+    const int patch = (int)(i * 8 / n);
+    float p[3] = {20.f * u(rng), 6.f * u(rng), 20.f * u(rng)};
+    p[patch % 3] = 1.5f * patch;                       // axis-aligned planes
+    float nv[3] = {0.f, 0.f, 0.f}; nv[patch % 3] = 1.f;
+    for (int k = 0; k < 3; ++k) { xyz[3 * i + k] = p[k]; nrm[3 * i + k] = nv[k]; }
+  }
+  for (size_t k = 0; k < 300; ++k) {                   // duplicates: row n/2 + 7k copies row 11k
+    for (int c = 0; c < 3; ++c) xyz[3 * (n / 2 + 7 * k) + c] = xyz[3 * (11 * k) + c];
+  }
+  std::vector<double> q(3 * Q);
+  for (size_t i = 0; i < Q; ++i) {
+    const size_t r = (size_t)(u(rng) * (n - 1));
+    for (int k = 0; k < 3; ++k) q[3 * i + k] = (double)xyz[3 * r + k] + (i < 300 ? 0.0 : g(rng));
+    if (i < 300) for (int k = 0; k < 3; ++k) q[3 * i + k] = (double)xyz[3 * (11 * i) + k];   // ON a duplicated point
+  }
+  pcd_cloud_options o;
+  pcd_cloud_options_default(&o);
+  o.raw_lidar_frame = 0;
+  pcd_cloud* single = nullptr;
+  CHECK_EQ((int)pcd_cloud_create(xyz.data(), nrm.data(), n, &o, &single), (int)PCD_OK);
+  std::vector<uint32_t> i0(Q), i1(Q); std::vector<float> d0(Q), d1(Q); std::vector<uint8_t> f0(Q), f1(Q);
+  CHECK_EQ((int)pcd_nn_query(single, q.data(), Q, i0.data(), d0.data(), f0.data()), (int)PCD_OK);
+  for (size_t i = 0; i < 300; ++i) CHECK(i0[i] == 11 * i && d0[i] == 0.f);   // the tie goes to the lower row
+  std::vector<double> ax(3 * Q), aa(4 * Q), ad(Q), ag(Q), bx(3 * Q), ba(4 * Q), bd(Q), bg(Q);
+  std::vector<uint8_t> at(Q), bt(Q);
+  const double range = 1.0;
+  pcd_assoc_out oa{ax.data(), aa.data(), at.data(), ad.data(), ag.data(), nullptr, nullptr, nullptr};
+  CHECK_EQ((int)pcd_associate(single, q.data(), Q, &range, 1, PCD_GATE_MAPPER_LOCAL, &oa), (int)PCD_OK);
+  const pcd_shard_reduce host_red{HostMinU64, HostSumI32, nullptr};
+  for (int nsh = 2; nsh <= 4; ++nsh) {
+    for (int use_cb = 0; use_cb < 2; ++use_cb) {
+      const int devs[4] = {0, 0, 0, 0};
+      pcd_cloud_shards* sh = nullptr;
+      CHECK_EQ((int)pcd_cloud_create_sharded(xyz.data(), nrm.data(), n, &o, devs, nsh, &sh), (int)PCD_OK);
+      CHECK_EQ(pcd_cloud_shards_count(sh), nsh);
+      CHECK_EQ((size_t)pcd_cloud_shards_size(sh), n);
+      const pcd_shard_reduce* red = use_cb ? &host_red : nullptr;
+      CHECK_EQ((int)pcd_nn_query_sharded(sh, q.data(), Q, red, i1.data(), d1.data(), f1.data()), (int)PCD_OK);
+      CHECK(i1 == i0 && f1 == f0 && std::memcmp(d1.data(), d0.data(), Q * sizeof(float)) == 0);
+      pcd_assoc_out ob{bx.data(), ba.data(), bt.data(), bd.data(), bg.data(), nullptr, nullptr, nullptr};
+      CHECK_EQ((int)pcd_associate_sharded(sh, q.data(), Q, &range, 1, PCD_GATE_MAPPER_LOCAL, red, &ob), (int)PCD_OK);
+      CHECK(bt == at && std::memcmp(bx.data(), ax.data(), 3 * Q * 8) == 0 && std::memcmp(ba.data(), aa.data(), 4 * Q * 8) == 0);
+      CHECK(std::memcmp(bd.data(), ad.data(), Q * 8) == 0 && std::memcmp(bg.data(), ag.data(), Q * 8) == 0);
+      pcd_cloud_shards_destroy(sh);
+    }
+  }
+  pcd_cloud_destroy(single);
+  return 0;
+}
+
 static int TestGpu() {
   if (pcd_device_count() < 1) { std::printf("FAIL: --gpu given but no gfx950 device\n"); return 1; }
   // cloud: plane y = 1 (visual frame) on a 5 cm lattice with normal (0,1,0), given in the raw LiDAR frame
@@ -689,7 +779,7 @@ static int TestGpu() {
   for (double r : res) s += r * r;
   CHECK(std::fabs(cost - 0.5 * s) <= 1e-9 * cost);
   CHECK(cost > 0 && cost < 300 * 8.0 + 1e4);   // +-2 px noise on 300 observations + one lidar term
-  return TestGpuProjection() + TestGpuSiftMatcher() + TestGpuCeresAdapterEndToEnd();
+  return TestGpuProjection() + TestGpuSiftMatcher() + TestGpuCeresAdapterEndToEnd() + TestGpuShardedCloud();
 }
 
 int main(int argc, char** argv) {

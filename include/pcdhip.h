@@ -98,6 +98,23 @@ pcd_status pcd_cloud_get_info(const pcd_cloud* c, pcd_cloud_info* info);
 pcd_status pcd_cloud_download(const pcd_cloud* c, float* xyz /*[size][3]*/, float* nrm /*[size][3]*/);
 
 /* ------------------------------------------------------------------------
+ * One cloud over several devices of this process.
+ * What IncrementalMapper::LoadPointcloud / BundleAdjustmentController::LoadPointcloud
+ * (sfm/incremental_mapper.cc:194-206, controllers/bundle_adjustment.cc:206-212)
+ * would build on a multi-GPU host: the cloud cut into ndev spatially compact
+ * shards, one per device; indices everywhere are the post-filter row indices
+ * of the WHOLE cloud, and every result equals the single-device one bit for
+ * bit (ties -> lowest index, also across shards).
+ * --------------------------------------------------------------------- */
+typedef struct pcd_cloud_shards pcd_cloud_shards;
+pcd_status pcd_cloud_create_sharded(const float* xyz, const float* nrm, uint64_t n, const pcd_cloud_options* opts,
+                                    const int* devices, int ndev, pcd_cloud_shards** out);  /* opts->device unused */
+void pcd_cloud_shards_destroy(pcd_cloud_shards* s);
+int pcd_cloud_shards_count(const pcd_cloud_shards* s);
+uint64_t pcd_cloud_shards_size(const pcd_cloud_shards* s);          /* rows kept after the NaN filter, all shards */
+pcd_cloud* pcd_cloud_shards_get(pcd_cloud_shards* s, int shard);    /* borrowed: shard `shard` as a pcd_cloud      */
+
+/* ------------------------------------------------------------------------
  * Nearest neighbour                          replaces lidar/kdtree.cc:10-21
  *   Kdtree::GetClosestPoint  (k = 1 pcl::KdTreeFLANN::nearestKSearch,
  *   FLANN L2_Simple<float> on x,y,z; exact)
@@ -222,6 +239,28 @@ pcd_status pcd_associate_from_payload_device(int device, const double* d_q_xyz, 
 pcd_status pcd_filter_lidar_outlier_device(int device, const double* d_points_xyz, const double* d_lidar_xyz,
                                            const uint8_t* d_type, uint64_t n, double max_proj_dist_error,
                                            double max_icp_dist_error, uint8_t* d_erase, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Sharded cloud (pcd_cloud_create_sharded above): search and association
+ * --------------------------------------------------------------------- */
+/* The exchange steps of the sharded search are reductions over the shards' device buffers: buf[s] lives on
+ * devices[s]; on return EVERY buf[s] must hold the element-wise result.  A C++ host plugs RCCL here
+ * (ncclGroupStart; ncclAllReduce(buf[s], buf[s], count, ncclUint64, ncclMin, comm[s], 0) per shard; ncclGroupEnd),
+ * tests an in-process loop.  NULL callbacks (or a NULL pcd_shard_reduce): the library reduces with peer copies to the
+ * first shard's device.  All devices are idle (synchronised) when a callback is entered; return 0 for success. */
+typedef struct {
+  int (*min_u64)(void* user, uint64_t* const* buf, const int* devices, int nshards, uint64_t count);
+  int (*sum_i32)(void* user, int32_t* const* buf, const int* devices, int nshards, uint64_t count);
+  void* user;
+} pcd_shard_reduce;
+
+/* pcd_nn_query / pcd_associate over the shards: home-shard search, MIN over shards, refinement of the queries a foreign
+ * shard's bounding box cannot rule out, MIN again (+ the winners' rows from their owners, SUM over shards). */
+pcd_status pcd_nn_query_sharded(pcd_cloud_shards* s, const double* q_xyz, uint64_t Q, const pcd_shard_reduce* red,
+                                uint32_t* idx, float* sqdist, uint8_t* found);
+pcd_status pcd_associate_sharded(pcd_cloud_shards* s, const double* q_xyz, uint64_t Q, const double* max_range,
+                                 uint64_t max_range_count, int gate_mode, const pcd_shard_reduce* red,
+                                 const pcd_assoc_out* out);
 
 /* ------------------------------------------------------------------------
  * Depth-projection association (LidarPointType::Proj)   replaces lidar/pcd_projection.{h,cc} `PcdProj`
