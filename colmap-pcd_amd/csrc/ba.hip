@@ -723,6 +723,84 @@ __global__ __launch_bounds__(256) void k_ba_lidar_raw(BaDev d, double* __restric
   if (JL) { JL[3 * l] = J[0]; JL[3 * l + 1] = J[1]; JL[3 * l + 2] = J[2]; }
 }
 
+// ---- post-BA filters, reduced per track (base/reconstruction.cc:1662-1712, :837-855, :906-921) -----------------
+// thread = point; its observations in ascending observation index (pt_obs_list)
+__global__ __launch_bounds__(256) void k_ba_filter_tracks(int P, const uint32_t* __restrict__ pt_start,
+                                                          const uint32_t* __restrict__ pt_list,
+                                                          const double* __restrict__ sq_err, double max_sq,
+                                                          uint8_t* __restrict__ obs_erase, uint8_t* __restrict__ point_delete,
+                                                          double* __restrict__ point_error, double* __restrict__ partial) {
+  __shared__ double s_f[4], s_e[4], s_n[4];
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  double filtered = 0.0, esum = 0.0, valid = 0.0;
+  if (p < P) {
+    const uint32_t b = pt_start[p], len = pt_start[p + 1] - b;
+    uint32_t ndel = 0;
+    double sum = 0.0;
+    for (uint32_t j = 0; j < len; ++j) {
+      const double e = sq_err[pt_list[b + j]];
+      if (e > max_sq) ++ndel; else sum += sqrt(e);
+    }
+    // reconstruction.cc:1677-1681 (length < 2) and :1700-1702 (at most one element survives): DeletePoint3D
+    const bool del = len < 2 || ndel + 1 >= len;
+    if (obs_erase)
+      for (uint32_t j = 0; j < len; ++j) {
+        const uint32_t o = pt_list[b + j];
+        obs_erase[o] = (del || sq_err[o] > max_sq) ? 1 : 0;
+      }
+    filtered = del ? (double)len : (double)ndel;
+    const double err = del ? -1.0 : sum / (double)(len - ndel);   // Track().Length() after the deletions (:1708)
+    if (point_delete) point_delete[p] = del ? 1 : 0;
+    if (point_error) point_error[p] = err;
+    if (!del) { esum = err; valid = 1.0; }
+  }
+  // fixed-order reduction: lanes by butterfly, the 4 wavefronts in order
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    filtered += __shfl_xor(filtered, off); esum += __shfl_xor(esum, off); valid += __shfl_xor(valid, off);
+  }
+  if (lane == 0) { s_f[wave] = filtered; s_e[wave] = esum; s_n[wave] = valid; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[3 * (size_t)blockIdx.x] = (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]);
+    partial[3 * (size_t)blockIdx.x + 1] = (s_e[0] + s_e[1]) + (s_e[2] + s_e[3]);
+    partial[3 * (size_t)blockIdx.x + 2] = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
+  }
+}
+__global__ __launch_bounds__(256) void k_ba_negative_depth(uint64_t O, const double* __restrict__ depth,
+                                                           uint8_t* __restrict__ flag, double* __restrict__ partial) {
+  __shared__ double s_c[4];
+  const uint64_t o = blockIdx.x * (uint64_t)256 + threadIdx.x;
+  const bool neg = o < O && depth[o] < 2.220446049250313e-16;   // !HasPointPositiveDepth (base/projection.cc:191-195)
+  if (o < O && flag) flag[o] = neg ? 1 : 0;
+  double c = neg ? 1.0 : 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s_c[0] + s_c[1]) + (s_c[2] + s_c[3]);
+}
+// one workgroup: partials added in block order (strided per thread, then the threads in order)
+__global__ __launch_bounds__(256) void k_ba_filter_summary(const double* __restrict__ part3, int nb3,
+                                                           const double* __restrict__ part1, int nb1,
+                                                           double* __restrict__ summary) {
+  __shared__ double s_v[4][256];
+  double a[4] = {0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nb3; b += 256) { a[0] += part3[3 * (size_t)b]; a[1] += part3[3 * (size_t)b + 1]; a[2] += part3[3 * (size_t)b + 2]; }
+  for (int b = threadIdx.x; b < nb1; b += 256) a[3] += part1[b];
+  for (int k = 0; k < 4; ++k) s_v[k][threadIdx.x] = a[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 256; ++i) for (int k = 0; k < 4; ++k) t[k] += s_v[k][i];
+    summary[0] = t[0];
+    summary[1] = t[2] > 0.0 ? t[1] / t[2] : 0.0;   // ComputeMeanReprojectionError: 0 when no point has an error
+    summary[2] = t[2];
+    summary[3] = t[3];
+  }
+}
+
 // rows of the variable-pose observations, packed: thread = 16-byte unit of an output row
 template <int N>   // doubles per row
 __global__ void k_pack_rows(const double* __restrict__ in, const uint32_t* __restrict__ vobs, uint64_t nrows,
@@ -766,6 +844,10 @@ struct pcd_ba {
   DevBuf<uint32_t> vobs;                 // [n_pose_rows] observation of every packed row
   DevBuf<double> p_jq, p_jt;             // packed pose Jacobians (only when some pose is constant)
   PinnedBuf<double> h_blocks;            // residuals | jac_q | jac_t | jac_X | jac_lidar | jac_cam
+  // pcd_ba_filter_tracks: the track CSR (point -> its observations, ascending), scratch
+  DevBuf<uint32_t> pt_obs_start, pt_obs_list;
+  DevBuf<double> f_sq, f_depth, f_part, f_summary;
+  DevBuf<uint8_t> f_u8;
   BaDev dev() const {
     BaDev d;
     d.cam_model = cam_model.p; d.cam_off = cam_off.p; d.cam_params = cam_params.p;
@@ -938,7 +1020,8 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
     const size_t nslots = slice_start[nslices];
     UP(pt_order, order.data(), order.size());
     UP(slice_start, slice_start.data(), slice_start.size());
-    // the track CSR is only needed to fill the ELL: it borrows the buffers of the lidar CSR uploaded right after
+    UP(pt_obs_start, st.data(), st.size()); UP(pt_obs_list, li.data(), li.size());   // kept: pcd_ba_filter_tracks
+    // the ELL fill borrows the buffers of the lidar CSR uploaded right after
     UP(pt_lidar_start, st.data(), st.size()); UP(pt_lidar_list, li.data(), li.size());
     pcd_status sa = b->sell_img.reserve(std::max<size_t>(nslots, 1));
     if (sa == PCD_OK) sa = b->sell_xy.reserve(std::max<size_t>(2 * nslots, 2));
@@ -1129,6 +1212,46 @@ pcd_status pcd_ba_observation_errors(pcd_ba* b, double* sq_err, double* depth) {
   PCD_TRY(pcd_ba_observation_errors_device(b, sq_err ? b->o_jq.p : nullptr, depth ? b->o_jt.p : nullptr, nullptr));
   if (sq_err) PCD_HIP_TRY(hipMemcpy(sq_err, b->o_jq.p, b->O * sizeof(double), hipMemcpyDeviceToHost));
   if (depth) PCD_HIP_TRY(hipMemcpy(depth, b->o_jt.p, b->O * sizeof(double), hipMemcpyDeviceToHost));
+  return PCD_OK;
+}
+
+pcd_status pcd_ba_filter_tracks_device(pcd_ba* b, double max_reproj_error, const pcd_ba_filter_out* o, void* stream) {
+  PCD_REQUIRE(b && o, "null pointer");
+  PCD_HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t O = b->O;
+  const int nbp = (int)div_up((uint64_t)b->P, 256), nbo = (int)div_up(std::max<uint64_t>(O, 1), 256);
+  PCD_TRY(b->f_sq.reserve(std::max<uint64_t>(O, 1))); PCD_TRY(b->f_depth.reserve(std::max<uint64_t>(O, 1)));
+  PCD_TRY(b->f_part.reserve(3 * (size_t)nbp + nbo + 4));
+  if (O) PCD_TRY(pcd_ba_observation_errors_device(b, b->f_sq.p, b->f_depth.p, s));
+  ScopedKernelTimer t("ba_filter_tracks", s);
+  double* part3 = b->f_part.p, *part1 = b->f_part.p + 3 * (size_t)nbp;
+  hipLaunchKernelGGL(k_ba_filter_tracks, dim3(nbp), dim3(256), 0, s, b->P, b->pt_obs_start.p, b->pt_obs_list.p, b->f_sq.p,
+                     max_reproj_error * max_reproj_error, o->obs_erase, o->point_delete, o->point_error, part3);
+  hipLaunchKernelGGL(k_ba_negative_depth, dim3(nbo), dim3(256), 0, s, O, b->f_depth.p, o->obs_negative_depth, part1);
+  if (o->summary) hipLaunchKernelGGL(k_ba_filter_summary, dim3(1), dim3(256), 0, s, part3, nbp, part1, nbo, o->summary);
+  PCD_HIP_TRY(hipGetLastError());
+  return PCD_OK;
+}
+
+pcd_status pcd_ba_filter_tracks(pcd_ba* b, double max_reproj_error, const pcd_ba_filter_out* o) {
+  PCD_REQUIRE(b && o, "null pointer");
+  PCD_HIP_TRY(hipSetDevice(b->device));
+  const size_t O = b->O, P = (size_t)b->P;
+  PCD_TRY(b->f_u8.reserve(2 * O + P + 1)); PCD_TRY(b->f_summary.reserve(P + 4));
+  pcd_ba_filter_out d{};
+  d.obs_erase = o->obs_erase ? b->f_u8.p : nullptr;
+  d.obs_negative_depth = o->obs_negative_depth ? b->f_u8.p + O : nullptr;
+  d.point_delete = o->point_delete ? b->f_u8.p + 2 * O : nullptr;
+  d.point_error = o->point_error ? b->f_summary.p + 4 : nullptr;
+  d.summary = o->summary ? b->f_summary.p : nullptr;
+  PCD_TRY(pcd_ba_filter_tracks_device(b, max_reproj_error, &d, nullptr));
+  if (o->obs_erase && O) PCD_HIP_TRY(hipMemcpy(o->obs_erase, d.obs_erase, O, hipMemcpyDeviceToHost));
+  if (o->obs_negative_depth && O) PCD_HIP_TRY(hipMemcpy(o->obs_negative_depth, d.obs_negative_depth, O, hipMemcpyDeviceToHost));
+  if (o->point_delete) PCD_HIP_TRY(hipMemcpy(o->point_delete, d.point_delete, P, hipMemcpyDeviceToHost));
+  if (o->point_error) PCD_HIP_TRY(hipMemcpy(o->point_error, d.point_error, P * sizeof(double), hipMemcpyDeviceToHost));
+  if (o->summary) PCD_HIP_TRY(hipMemcpy(o->summary, d.summary, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  PCD_HIP_TRY(hipDeviceSynchronize());
   return PCD_OK;
 }
 

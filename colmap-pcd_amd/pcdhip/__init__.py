@@ -110,7 +110,7 @@ ABI_SYMBOLS = [
     "pcd_proj_last_pairs", "pcd_proj_scale_coeffs", "pcd_proj_set_new_images",
     "pcd_sift_matcher_create", "pcd_sift_matcher_destroy", "pcd_sift_matcher_set_max_sift",
     "pcd_sift_matcher_set_descriptors", "pcd_sift_matcher_match",
-    "pcd_ba_evaluate_blocks",
+    "pcd_ba_evaluate_blocks", "pcd_ba_filter_tracks", "pcd_ba_filter_tracks_device",
     "pcd_cloud_create_sharded", "pcd_cloud_shards_destroy", "pcd_cloud_shards_count", "pcd_cloud_shards_size",
     "pcd_cloud_shards_get", "pcd_nn_query_sharded", "pcd_associate_sharded",
 ]
@@ -711,6 +711,23 @@ class BA:
         L.pcd_ba_observation_errors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _check(L.pcd_ba_observation_errors(self._h, _vp(sq), _vp(depth)))
         return sq, depth
+
+    def filter_tracks(self, max_reproj_error):
+        """post-BA filters reduced per track on the device (pcd_ba_filter_tracks): dict of obs_erase [O],
+        obs_negative_depth [O], point_delete [P], point_error [P] (-1: no error), num_filtered, mean_reproj_error,
+        num_points_with_error, num_negative_depth"""
+        class FO(C.Structure):
+            _fields_ = [(n, C.c_void_p) for n in ("obs_erase", "obs_negative_depth", "point_delete", "point_error", "summary")]
+        out = dict(obs_erase=np.zeros(self.O, np.uint8), obs_negative_depth=np.zeros(self.O, np.uint8),
+                   point_delete=np.zeros(self.P, np.uint8), point_error=np.zeros(self.P), summary=np.zeros(4))
+        fo = FO(*[_vp(out[k]) for k in ("obs_erase", "obs_negative_depth", "point_delete", "point_error", "summary")])
+        L = lib()
+        L.pcd_ba_filter_tracks.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+        _check(L.pcd_ba_filter_tracks(self._h, float(max_reproj_error), C.byref(fo)))
+        sm = out.pop("summary")
+        out.update(num_filtered=int(sm[0]), mean_reproj_error=float(sm[1]), num_points_with_error=int(sm[2]),
+                   num_negative_depth=int(sm[3]))
+        return out
 
     def device_parameters(self):
         a, b = C.c_void_p(), C.c_void_p()

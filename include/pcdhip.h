@@ -441,6 +441,29 @@ typedef struct {
 
 pcd_status pcd_ba_evaluate(pcd_ba* ba, const pcd_ba_out* out);                 /* host outputs   */
 
+/* Post-BA filters reduced PER TRACK on the device, from the parameters resident after BA:
+ *   Reconstruction::FilterPoints3DWithLargeReprojectionError   base/reconstruction.cc:1662-1712
+ *   Reconstruction::FilterObservationsWithNegativeDepth        base/reconstruction.cc:837-855
+ *   Reconstruction::ComputeMeanReprojectionError               base/reconstruction.cc:906-921
+ * A track = all observations of a point in this problem (AddPointToProblem adds the observations from images outside
+ * the config too, optim/bundle_adjustment.cc:927-985, so for the points of a BA config that is the whole track).
+ * Per point: track shorter than 2 -> deleted; an element whose squared error (normalised quaternion, DBL_MAX behind
+ * the camera, base/projection.cc:104-117) exceeds max_reproj_error^2 is erased; if at most one element would survive
+ * the point is deleted with all its elements; otherwise Point3D::SetError(sum of sqrt(error) of the kept elements /
+ * their number).  Sums run in ascending observation index.  Every pointer may be NULL.  The erase / bookkeeping on
+ * the Reconstruction itself stays with the caller. */
+typedef struct {
+  uint8_t* obs_erase;            /* [O] 1: DeleteObservation (or its point is deleted)                       */
+  uint8_t* obs_negative_depth;   /* [O] 1: !HasPointPositiveDepth (depth < eps)                              */
+  uint8_t* point_delete;         /* [P] 1: DeletePoint3D                                                     */
+  double* point_error;           /* [P] Point3D::Error() after the filter; -1 = HasError() false (deleted)   */
+  double* summary;               /* [4] num_filtered (the function's return value), mean reprojection error  */
+                                 /*     over the points with an error (0 if none), number of such points,     */
+                                 /*     number of observations with negative depth                            */
+} pcd_ba_filter_out;
+pcd_status pcd_ba_filter_tracks_device(pcd_ba* ba, double max_reproj_error, const pcd_ba_filter_out* d_out, void* stream);
+pcd_status pcd_ba_filter_tracks(pcd_ba* ba, double max_reproj_error, const pcd_ba_filter_out* out);   /* host outputs */
+
 /* The Ceres route (optim/bundle_adjustment.cc:858-893, :967-983, :1031-1037: every residual block's Evaluate copies
  * its rows): the raw blocks of ALL residual blocks land in PINNED host buffers owned by the handle -- one device pass,
  * then one asynchronous copy per array at the pinned PCIe rate instead of pcd_ba_evaluate's synchronous copies into

@@ -420,6 +420,50 @@ class BA:
         return cost, Himg, gimg, Hpt, gpt, W
 
 
+def filter_tracks(sq_err, depth, obs_point, num_points, max_reproj_error):
+    """Per-track reduce of the post-BA filters, restated from the reference (test infrastructure):
+      Reconstruction::FilterPoints3DWithLargeReprojectionError  base/reconstruction.cc:1662-1712
+      Reconstruction::FilterObservationsWithNegativeDepth       base/reconstruction.cc:837-855 (base/projection.cc:191-195)
+      Reconstruction::ComputeMeanReprojectionError              base/reconstruction.cc:906-921
+    sq_err / depth per observation (BA.observation_errors), obs_point [O] the point of every observation; a track =
+    the observations of a point in ascending observation index.  Plain Python loops: small cases only."""
+    O = len(obs_point)
+    tracks = [[] for _ in range(num_points)]
+    for o in range(O):
+        tracks[int(obs_point[o])].append(o)
+    max_sq = max_reproj_error * max_reproj_error
+    obs_erase = np.zeros(O, np.uint8)
+    point_delete = np.zeros(num_points, np.uint8)
+    point_error = np.full(num_points, -1.0)
+    num_filtered = 0
+    for p, tr in enumerate(tracks):
+        if len(tr) < 2:                                  # :1677-1681
+            num_filtered += len(tr)
+            point_delete[p] = 1
+            obs_erase[tr] = 1
+            continue
+        to_delete, err_sum = [], 0.0
+        for o in tr:                                     # :1687-1698
+            if sq_err[o] > max_sq:
+                to_delete.append(o)
+            else:
+                err_sum += np.sqrt(sq_err[o])
+        if len(to_delete) >= len(tr) - 1:                # :1700-1702
+            num_filtered += len(tr)
+            point_delete[p] = 1
+            obs_erase[tr] = 1
+        else:                                            # :1703-1709 (DeleteObservation shortens the track first)
+            num_filtered += len(to_delete)
+            obs_erase[to_delete] = 1
+            point_error[p] = err_sum / (len(tr) - len(to_delete))
+    has = point_error >= 0
+    mean = float(point_error[has].sum() / has.sum()) if has.any() else 0.0      # :906-921
+    neg = (np.asarray(depth) < np.finfo(np.float64).eps).astype(np.uint8)       # !HasPointPositiveDepth
+    return dict(obs_erase=obs_erase, obs_negative_depth=neg, point_delete=point_delete, point_error=point_error,
+                num_filtered=num_filtered, mean_reproj_error=mean, num_points_with_error=int(has.sum()),
+                num_negative_depth=int(neg.sum()))
+
+
 # ------------------------------------------------- depth projection (N1) ----
 class ProjOptions(C.Structure):
     """lidar/pcd_projection.h:31-47 (the numeric members)."""

@@ -98,3 +98,37 @@ def check_camera_model_round_trips(backend, inverse_backend):
         assert ok.all(), (case, "Newton inverse diverged")
         xy_back = fwd(uv)
         assert np.abs(xy_back - np.stack([X0, Y0], axis=1)).max() < tol, case
+
+
+def check_filters(backend):
+    """reconstruction_test.cc:394-445, :510-533, :599-614 through `backend.filter_tracks(model, cam, poses [I][7],
+    points [P][3], obs_image, obs_point, obs_xy, max_reproj_error)` -> dict as pcdhip.BA.filter_tracks"""
+    k = KATS["filter_points3d"]
+    pose = list(k["qvec"]) + list(k["tvec"])
+    for c in k["cases"]:
+        n = len(c["track_images"])
+        r = backend.filter_tracks(k["model"], k["camera_params"], [pose, pose], [c["point3D"]], list(range(n)), [0] * n,
+                                  [k["obs"]] * n, c["max_reproj_error"])
+        assert bool(r["point_delete"][0]) == c["deleted"], (c, r)
+        assert r["num_filtered"] == (n if c["deleted"] else 0), (c, r)
+        assert list(r["obs_erase"]) == [1 if c["deleted"] else 0] * n
+        if not c["deleted"]:
+            assert r["num_points_with_error"] == 1 and r["point_error"][0] >= 0
+    # negative depth: point (0, 0, z) in image 1 (and a second image so that the track has two elements)
+    for c in KATS["filter_negative_depth"]["cases"]:
+        r = backend.filter_tracks(0, [1.0, 0.0, 0.0], [[1, 0, 0, 0, 0, 0, 0]] * 2, [[0.0, 0.0, c["z"]]], [0, 1], [0, 0],
+                                  [[0.0, 0.0]] * 2, 1e300)
+        assert list(r["obs_negative_depth"]) == [int(c["erased"])] * 2 and r["num_negative_depth"] == 2 * int(c["erased"]), (c, r)
+    # mean reprojection error = mean of the surviving points' errors: points with a 2-element track whose elements
+    # both miss by exactly e pixels get Error() = e
+    for c in KATS["mean_reprojection_error"]["cases"]:
+        errs = c["point_errors"]
+        P = max(len(errs), 1)
+        pts = [[0.0, 0.0, 1.0]] * P
+        oi, op, oxy = [], [], []
+        for p, e in enumerate(errs):
+            oi += [0, 1]; op += [p, p]; oxy += [[e, 0.0], [0.0, e]]
+        if not errs:                                   # no point has an error: a single-element track is deleted
+            oi, op, oxy = [0], [0], [[0.0, 0.0]]
+        r = backend.filter_tracks(0, [1.0, 0.0, 0.0], [[1, 0, 0, 0, 0, 0, 0]] * 2, pts, oi, op, oxy, 1e3)
+        assert r["mean_reproj_error"] == c["mean"], (c, r)

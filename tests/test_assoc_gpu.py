@@ -211,7 +211,7 @@ def test_gate_bounded_search(gpu, oracle, mode):
 
 
 @pytest.mark.parametrize("Q", [20000, 90000], ids=["one-launch path", "grid path"])
-def test_gate_bounded_search_far_from_origin(gpu, Q):
+def test_gate_bounded_search_far_from_origin(gpu, oracle, Q):
     """A cloud 8 km from the origin: float(query) is off by up to half a millimetre per axis there, so the float
     distance the search minimises and the double distance the gate tests differ by ~1e-3 m -- more than any relative
     slack on R^2.  The bound must widen by the query's float rounding (nn.hip bounded_init_key), or associations whose
@@ -233,4 +233,12 @@ def test_gate_bounded_search_far_from_origin(gpu, Q):
     assert 0.2 * Q < acc.sum() < 0.9 * Q
     for k in ("lidar_xyz", "abcd", "dist", "angle"):
         assert np.array_equal(a0[k][acc], a1[k][acc], equal_nan=True), k   # angle is 0/0 for a query on its point
+    # the unbounded path itself against the oracle on a sample (not only GPU against GPU)
+    sel = rng.choice(Q, min(Q, 800), replace=False)
+    idx, sq, found = oracle.nn_bruteforce(xyz, q[sel])
+    out6, ok = oracle.search_nearest_neibor(xyz, nrm, idx, found)
+    abcd, typ, dist, ang, d2p = oracle.associate(q[sel], out6, ok, mr[sel], 0)
+    assert np.array_equal(a0["type"][sel], typ) and np.array_equal(a0["nn_idx"][sel], idx)
+    hit = typ != 0
+    np.testing.assert_allclose(a0["dist"][sel][hit], dist[hit], rtol=1e-12)
     c.close()

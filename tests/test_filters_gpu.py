@@ -47,3 +47,34 @@ def test_filter_lidar_outlier(gpu, oracle):
     got = out.cpu().numpy()
     assert np.array_equal(got, exp)
     assert got[typ == 0].sum() == 0 and 0 < got.sum() < n
+
+
+def test_filter_tracks_against_oracle(gpu, oracle):
+    """per-track reduce of FilterPoints3DWithLargeReprojectionError / FilterObservationsWithNegativeDepth /
+    ComputeMeanReprojectionError (base/reconstruction.cc:1662-1712, :837-855, :906-921) on a scene with short tracks,
+    points behind cameras, unobserved points and large errors: every flag equal, errors and mean at 1e-12"""
+    s = synth.ba_scene(12, 4000, seed=43)
+    rng = np.random.default_rng(5)
+    s["points"][::40, 2] += 80.0                          # behind their cameras
+    s["obs_xy"][rng.integers(0, len(s["obs_xy"]), 600)] += rng.normal(0, 30, (600, 2))   # gross errors
+    keep = np.ones(len(s["obs_point"]), bool)
+    keep[np.isin(s["obs_point"], np.arange(0, 4000, 17))] = False    # points without observations
+    first = np.unique(s["obs_point"], return_index=True)[1]
+    only_one = np.isin(s["obs_point"], np.arange(5, 4000, 23))       # tracks of length 1
+    keep &= ~only_one | np.isin(np.arange(len(keep)), first)
+    for k in ("obs_image", "obs_point", "obs_xy"):
+        s[k] = s[k][keep]
+    ob = oracle.BA(**s)
+    sq, depth = ob.observation_errors()
+    for max_err in (4.0, 1.0, 0.0):
+        exp = oracle.filter_tracks(sq, depth, s["obs_point"], 4000, max_err)
+        ba = gpu.BA(**s)
+        got = ba.filter_tracks(max_err)
+        for k in ("obs_erase", "obs_negative_depth", "point_delete"):
+            assert np.array_equal(got[k], exp[k]), (max_err, k)
+        for k in ("num_filtered", "num_points_with_error", "num_negative_depth"):
+            assert got[k] == exp[k], (max_err, k, got[k], exp[k])
+        np.testing.assert_allclose(got["point_error"], exp["point_error"], rtol=1e-12, atol=1e-12)
+        assert abs(got["mean_reproj_error"] - exp["mean_reproj_error"]) <= 1e-12 * max(1.0, exp["mean_reproj_error"])
+        assert 0 < exp["point_delete"].sum() < 4000 and exp["num_negative_depth"] > 0
+        ba.close()

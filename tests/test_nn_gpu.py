@@ -268,22 +268,63 @@ def test_full_size_properties(gpu, N, Q):
     same_pt = order[(kk & np.uint64(0xFFFFFFFF)).astype(np.int64)]                   # back to original rows
     ref_i = (ref & np.uint64(0xFFFFFFFF)).astype(np.int64)
     diff = same_pt != ref_i
-    # a different row only on an exact distance tie (the compact order has its own lowest index)
-    assert np.array_equal(xyz[same_pt[diff]], xyz[ref_i[diff]]) or diff.sum() <= 8
+    # a different row only on an exact tie of the FLOAT distance to the query (the compact order has its own lowest
+    # index): the distance bits are equal for every row (checked above), so what remains to exclude is a wrong row that
+    # happens to carry the same bits -- recompute both rows' distances to the query in FLANN's arithmetic, zero tolerance
+    def l2(qf, p):
+        d = (qf[:, 0] - p[:, 0]) * (qf[:, 0] - p[:, 0])
+        d = d + (qf[:, 1] - p[:, 1]) * (qf[:, 1] - p[:, 1])
+        return d + (qf[:, 2] - p[:, 2]) * (qf[:, 2] - p[:, 2])
+    qf = q[:Qs].astype(np.float32)[diff]
+    da, db = l2(qf, xyz[same_pt[diff]]), l2(qf, xyz[ref_i[diff]])
+    assert np.array_equal(da.view(np.uint32), db.view(np.uint32)), "a differing row that is not an exact distance tie"
+    assert np.array_equal(da.view(np.uint32), (ref[diff] >> np.uint64(32)).astype(np.uint32))
     for s_ in sh:
         s_.close()
 
 
 @pytest.mark.parametrize("offset", [1e3, 1e5, 3e6])
-def test_far_from_origin(gpu, offset):
+def test_far_from_origin(gpu, oracle, offset):
     """coordinates with few mantissa bits left for the cell arithmetic (float spacing 0.25 m at 3e6): the
     binning slack sends more queries to the exact fallback, the result stays bit-exact"""
     xyz, nrm = synth.cloud_planes(300_000, seed=3)
     xyz = (xyz.astype(np.float64) + offset).astype(np.float32)
     q = synth.queries(xyz, 30_000, seed=4)
     c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
-    _check_exact(c.nn(q, gpu.NN_GRID), c.nn(q, gpu.NN_BRUTEFORCE), f"grid vs brute force at offset {offset}")
-    _check_exact(c.nn(q), c.nn(q, gpu.NN_BRUTEFORCE), f"auto vs brute force at offset {offset}")
+    bf = c.nn(q, gpu.NN_BRUTEFORCE)
+    _check_exact(c.nn(q, gpu.NN_GRID), bf, f"grid vs brute force at offset {offset}")
+    _check_exact(c.nn(q), bf, f"auto vs brute force at offset {offset}")
+    # ... and the GPU brute force itself against the oracle on a sample (not only GPU against GPU)
+    sel = np.random.default_rng(6).choice(len(q), 600, replace=False)
+    exp = oracle.nn_bruteforce(xyz, q[sel])
+    _check_exact(tuple(a[sel] for a in bf), exp, f"brute force vs oracle at offset {offset}")
+    c.close()
+
+
+def test_config_A_one_launch_path(gpu, oracle):
+    """BASELINE config A (Smith Hall 25-like): 2 M-point cloud, 20 k queries per call -- PCD_NN_AUTO takes the one-launch
+    path (k_nn_fallback<1 / 2>) at this batch size.  Plain search against the KD-tree oracle (bit-exact), gate-bounded
+    association against the unbounded one + gate."""
+    xyz, nrm = synth.cloud_planes(2_000_000)
+    q = synth.queries(xyz, 20_000, seed=3)
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    kd = oracle.KDTree(xyz)
+    exp = kd.query_mt(q, 8)
+    _check_exact(c.nn(q, gpu.NN_AUTO), exp, "config A, one launch, plain")
+    _check_exact(c.nn(q, gpu.NN_GRID), exp, "config A, grid path")
+    mr = synth.max_range_schedule(20_000, seed=3)
+    a0 = c.associate(q, mr, gpu.GATE_MAPPER_LOCAL)
+    a1 = c.associate(q, mr, gpu.GATE_MAPPER_LOCAL | gpu.GATE_BOUNDED_SEARCH)
+    assert np.array_equal(a0["type"], a1["type"])
+    acc = a0["type"] != 0
+    assert acc.sum() > 10_000
+    for k in ("lidar_xyz", "abcd", "dist", "angle", "nn_idx"):
+        assert np.array_equal(a0[k][acc], a1[k][acc]), k
+    # the accepted associations against the oracle's epilogue on the KD-tree's winners
+    out6, ok = oracle.search_nearest_neibor(xyz, nrm, exp[0], exp[2])
+    abcd, typ, dist, ang, d2p = oracle.associate(q, out6, ok, mr, 0)
+    assert np.array_equal(a0["type"], typ)
+    np.testing.assert_allclose(a0["abcd"][acc], abcd[acc], rtol=1e-12, atol=1e-300)
     c.close()
 
 

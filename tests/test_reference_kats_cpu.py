@@ -24,6 +24,21 @@ class OracleBackend:
         return ob.residuals().reshape(n, 2)
 
 
+def _filter_tracks_oracle(po, model, cam, poses, points, obs_image, obs_point, obs_xy, max_err):
+    ob = po.BA([model], [cam], poses, [0] * len(poses), points, np.asarray(obs_image, np.int32), np.asarray(obs_point, np.int32),
+               np.asarray(obs_xy, np.float64).reshape(-1, 2))
+    sq, depth = ob.observation_errors()
+    return po.filter_tracks(sq, depth, np.asarray(obs_point, np.int32), len(points), max_err)
+
+
+def test_filter_kats(oracle):
+    """reconstruction_test.cc:394-445, :510-533, :599-614 on the oracle's restatement of the per-track filters"""
+    class B(OracleBackend):
+        def filter_tracks(self, *a):
+            return _filter_tracks_oracle(self.po, *a)
+    refkats.check_filters(B(oracle))
+
+
 def test_squared_reprojection_error(oracle):
     refkats.check_squared_reprojection_error(OracleBackend(oracle))
 

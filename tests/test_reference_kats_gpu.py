@@ -1,6 +1,6 @@
 """The HIP path (through the C ABI) against the vectors the reference's own tests hold
 (tests/golden/reference_kats.json): projection_test.cc:95-124,180-222, pose_test.cc:168-186,
-camera_models_test.cc:133-217.  Same checks as tests/test_reference_kats_cpu.py runs on the oracle."""
+camera_models_test.cc:133-217, reconstruction_test.cc:394-445, 510-533, 599-614.  Same checks as tests/test_reference_kats_cpu.py runs on the oracle."""
 import numpy as np
 import pytest
 
@@ -31,6 +31,18 @@ class GpuBackend:
         r = ba.evaluate(("residuals",))["residuals"].reshape(n, 2)
         ba.close()
         return r
+
+
+def test_filter_kats(gpu):
+    """reconstruction_test.cc:394-445, :510-533, :599-614 on the device's per-track filter reduce"""
+    class B(GpuBackend):
+        def filter_tracks(self, model, cam, poses, points, obs_image, obs_point, obs_xy, max_err):
+            ba = self.gpu.BA([model], [cam], poses, [0] * len(poses), points, np.asarray(obs_image, np.int32),
+                             np.asarray(obs_point, np.int32), np.asarray(obs_xy, np.float64).reshape(-1, 2))
+            r = ba.filter_tracks(max_err)
+            ba.close()
+            return r
+    refkats.check_filters(B(gpu))
 
 
 def test_squared_reprojection_error(gpu):
