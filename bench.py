@@ -345,6 +345,28 @@ def main():
                                       "ms_per_step, for a like-for-like strong-scaling ratio")
             del dq_c, dmr_c
         del raw, res_only
+        if world == 1:
+            # the same scene with point ids that follow the images (synth.ba_scene coherent=True): what an incremental
+            # reconstruction's numbering looks like; the headline scene gives every point a random anchor image
+            sc_c = synth.ba_scene(a.cams, a.points, seed=11, order="image", coherent=True)
+            ba_c = pcdhip.BA(**sc_c, device=local_rank)
+            Oc = ba_c.O
+            Wc = f64(max(Oc, 1), 18)
+            full_c = dict(cost=cost_j, H_img=H_img, g_img=g_img, H_pt=H_pt, g_pt=g_pt, W=Wc)
+
+            def ba_c_step():
+                ba_c.evaluate_device(full_c, stream)
+                ba_c.evaluate_device(resid_only, stream)
+            for _ in range(2):
+                ba_c_step()
+            pcdhip.profile_enable(True); pcdhip.profile_reset()
+            t_c = timed(ba_c_step, a.steps, sync)
+            pc = pcdhip.profile_get(); pcdhip.profile_enable(False)
+            extras["ba_coherent_scene"] = dict(
+                note="same cameras / tracks, point ids ascending with the anchor image (incremental-reconstruction numbering)",
+                ba_iter_ms=t_c * 1e3, kernel_ms={k: round(ms / n, 4) for k, (n, ms) in sorted(pc.items()) if k.startswith("ba_")})
+            ba_c.close()
+            del Wc
         # ---- what the call sites need: the search bounded by each query's gate (PCD_GATE_BOUNDED_SEARCH) --------
         # same recorded associations, same field values (tests/test_assoc_gpu.py::test_gate_bounded_search); the
         # headline above keeps the unbounded exact search for every query

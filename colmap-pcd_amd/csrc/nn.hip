@@ -801,6 +801,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
         // the same exact bound as the pyramid nodes and only the survivors are scanned -- no cell_start round trip,
         // and roughly half the points of a block that a plane crosses never leave HBM.
         uint32_t rs = 0, rn = 0;
+        float sl = INFINITY;   // lanes 0..7: exact lower bound of the lane's sub-block (inf: empty)
         if (lane < 8) {
           const uint64_t blk = ((uint64_t)nz * g.bdims[1] + ny) * g.bdims[0] + nx;
           const float4 lo = *reinterpret_cast<const float4*>(sub_aabb + 8 * (blk * 8 + lane));      // lo.xyz hi.x
@@ -809,44 +810,38 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
           if (cnt) {
             const float px = fminf(fmaxf(qx, lo.x), lo.w), pyc = fminf(fmaxf(qy, lo.y), hi.x),
                         pz = fminf(fmaxf(qz, lo.z), hi.y);
-            if (l2_simple3(qx, qy, qz, px, pyc, pz) <= best_d) { rs = __float_as_uint(hi.z); rn = cnt; }
+            sl = l2_simple3(qx, qy, qz, px, pyc, pz);
+            rs = __float_as_uint(hi.z); rn = cnt;
           }
         }
-        // The surviving ranges are scanned as one concatenated range, 256 points per step, with the four loads of
-        // a step issued back to back (clamped indices, no branches around them).  Range starts and source
-        // deltas are wave-uniform (SGPRs): slot -> address is seven compares, no LDS.
-        uint32_t Tb;
-        const uint32_t roff = wave_excl_scan_u32(rn, Tb);
-        uint32_t o[8], dd[8];
+        // Sub-blocks NEAREST FIRST, the best distance updated after each: the first one usually brings the bound down
+        // to the query's true distance and the other seven fail their test -- scanning all survivors of the test
+        // against the bound the block was ENTERED with (round 2) read ~1 760 points per query, most of them in the
+        // first block of a walk, whose bound is still infinite.
+        while (true) {
+          const unsigned long long mm = __ballot(sl <= best_d);
+          if (mm == 0) break;
+          const int r = wave_argmin_u32(__float_as_uint(sl), mm);   // wave-uniform
+          const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)rs, r), n0 = (uint32_t)__builtin_amdgcn_readlane((int)rn, r);
+          if (lane == r) sl = INFINITY;
+          for (uint32_t base = 0; base < n0; base += 64 * kFbLoads) {
+            float4 p[kFbLoads];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          o[k] = (uint32_t)__builtin_amdgcn_readlane((int)roff, k);
-          dd[k] = (uint32_t)__builtin_amdgcn_readlane((int)rs, k) - o[k];
-        }
-        for (uint32_t base = 0; base < Tb; base += 64 * kFbLoads) {
-          float4 p[kFbLoads];
+            for (int k = 0; k < kFbLoads; ++k) {   // clamped indices, no branches around the loads: a re-read is harmless
+              const uint32_t gi = base + k * 64 + lane;
+              p[k] = sorted[s0 + (gi < n0 ? gi : n0 - 1)];
+            }
 #pragma unroll
-          for (int k = 0; k < kFbLoads; ++k) {
-            uint32_t gi = base + k * 64 + lane;
-            gi = gi < Tb ? gi : Tb - 1;
-            // empty ranges share their offset with the next one: test from the last range down
-            uint32_t dl = dd[0];
-#pragma unroll
-            for (int r = 1; r < 8; ++r) dl = gi >= o[r] ? dd[r] : dl;
-            p[k] = sorted[gi + dl];
-          }
-#pragma unroll
-          for (int k = 0; k < kFbLoads; ++k) {
-            if (base + k * 64 + lane < Tb) {
+            for (int k = 0; k < kFbLoads; ++k) {
               const float d = l2_simple3(qx, qy, qz, p[k].x, p[k].y, p[k].z);
               const uint64_t key = make_key(d, __float_as_uint(p[k].w));
               lane_best = key < lane_best ? key : lane_best;
             }
           }
+          st_pts += n0;
+          best = wave_min_u64(lane_best);
+          best_d = __uint_as_float((uint32_t)(best >> 32));
         }
-        st_pts += Tb;
-        best = wave_min_u64(lane_best);
-        best_d = __uint_as_float((uint32_t)(best >> 32));
       } else {
         --lev;
         expand = true;

@@ -118,14 +118,18 @@ OPENCV_PARAMS = [3039.0, 3039.0, 2016.0, 1512.0, -0.05, 0.01, 1e-4, 1e-4]
 
 
 def ba_scene(num_cams, num_points, seed=11, mean_extra=4.0, lidar_frac=0.9, const_pose_frac=0.0,
-             max_track=30, scene_box=BOX, order="point"):
+             max_track=30, scene_box=BOX, order="point", coherent=False):
     """Returns a dict of flat arrays for pcdhip.BA / oracle BA.
 
     Cameras sit on a path along x at y ~ 2 m, looking roughly along +z/-z; each point is observed by
     L cameras (L = clip(Geom(0.25)+2, 2, max_track)) chosen among those nearest in x; the observation is
     the exact projection + U(-2,2) px; poses are then perturbed.
     order = "point": observations grouped by track; "image": grouped by image (stable), the order in which
-    BundleAdjuster::AddImageToProblem creates the residual blocks (optim/bundle_adjustment.cc:814-919)."""
+    BundleAdjuster::AddImageToProblem creates the residual blocks (optim/bundle_adjustment.cc:814-919).
+    coherent = True: the point ids follow the images that see them (point ids ascend with the anchor image), the way an
+    incremental reconstruction numbers its points -- every image triangulates new points as it is registered, so the
+    points an image observes are neighbours in id space.  The default gives every point a RANDOM anchor image, the
+    worst case for the per-observation point gathers."""
     rng = np.random.default_rng(seed)
     cams_x = np.linspace(5, scene_box[0] - 5, num_cams)
     poses_true = np.empty((num_cams, 7))
@@ -191,6 +195,17 @@ def ba_scene(num_cams, num_points, seed=11, mean_extra=4.0, lidar_frac=0.9, cons
     ground = rng.random(nl) < 0.35
     weight = np.where(ground, 1000.0, 100.0)    # global-BA defaults, optim/bundle_adjustment.h:59-63
     const_pose = (rng.random(num_cams) < const_pose_frac).astype(np.uint8)
+    if coherent:
+        perm = np.argsort(anchor, kind="stable")              # new id -> old id
+        new_id = np.empty(num_points, np.int64); new_id[perm] = np.arange(num_points)
+        points = points[perm]
+        obs_point = new_id[obs_point].astype(np.int32)
+        if order == "point":
+            o2 = np.argsort(obs_point, kind="stable")
+            obs_image, obs_point, obs_xy = obs_image[o2], obs_point[o2], obs_xy[o2]
+        lp_new = new_id[lidar_point]
+        o3 = np.argsort(lp_new, kind="stable")
+        lidar_point, abcd, weight = lp_new[o3].astype(np.int32), abcd[o3], weight[o3]
     return dict(cam_model=np.array([4], np.int32), cam_params_list=[OPENCV_PARAMS], poses=poses,
                 image_camera=np.zeros(num_cams, np.int32), points=points, obs_image=obs_image,
                 obs_point=obs_point, obs_xy=obs_xy, lidar_point=lidar_point, lidar_abcd=abcd,
