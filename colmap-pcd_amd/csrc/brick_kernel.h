@@ -4,9 +4,10 @@
 // The quad rows (grid.h: 2x2 cells in (y,z), contiguous along x) of the brick grown by R cells are contiguous
 // ranges of the cell-sorted cloud -- 9 ranges for B = R = 2; their concatenation is streamed through two
 // 256-point LDS tiles per wavefront:
-//   * slot -> source address needs no search: range starts live one per lane in a VGPR, a wave-uniform cursor
-//     follows the 64-slot window of each DMA instruction and only the range boundaries inside the window
-//     (0.6 on average) cost a v_readlane + compare + select;
+//   * slot -> source address: the concatenation is addressed in groups of 4 consecutive slots (every range padded to
+//     a multiple of 4 records), lane l of tile t owns group 64 t + l and finds its range with one v_cmp + v_cndmask
+//     per range start (starts wave-uniform in SGPRs, source - start deltas in VGPRs); the tile's four DMA
+//     instructions are that one address + 0 / 16 / 32 / 48 bytes of immediate offset;
 //   * staging is LDS-DMA (global_load_lds_dwordx4: one 16-B record per lane, no VGPR round trip);
 //     the 4 DMAs of tile t+1 are in flight while tile t is compared (counted s_waitcnt vmcnt(4));
 //   * compare: lanes = staged points (ds_read_b128), the G queries are wave-uniform (SGPRs), every

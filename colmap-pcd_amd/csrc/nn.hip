@@ -728,6 +728,10 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
   __shared__ float s_lb[4][kMaxPyrLevels][64];
   __shared__ unsigned long long s_mask[4][kMaxPyrLevels];
   __shared__ int s_node[4][kMaxPyrLevels][3];
+  __shared__ int4 s_pyr[kMaxPyrLevels];   // per level {dims x, y, z, node offset}
+  if (threadIdx.x < (unsigned)kMaxPyrLevels)
+    s_pyr[threadIdx.x] = make_int4(py.dims[threadIdx.x][0], py.dims[threadIdx.x][1], py.dims[threadIdx.x][2], (int)py.off[threadIdx.x]);
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform for the compiler: LDS addresses on the scalar unit
   const uint32_t count = count_ptr ? *count_ptr : count_imm;
@@ -763,20 +767,21 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
     bool expand = true;
     while (true) {
       if (expand) {
-        // children of node (nx,ny,nz) of level `lev` live on level lev-1
+        // children of node (nx,ny,nz) of level `lev` live on level lev-1.  ONE memory round trip per expansion: the
+        // level's dimensions and offset come from LDS (as kernel arguments indexed by `lev` they were four dependent
+        // scalar loads), the child's two 16-byte loads are unconditional on a clamped index and the bound is selected
+        // afterwards (under `if (non-empty)` the compiler split them into a first pair of dwords, the test, and a
+        // second, dependent pair of loads): the walk is a chain of such steps and its latency is the kernel's time.
         const int cx = 4 * nx + ci, cy = 4 * ny + cj, cz = 4 * nz + ck;
-        const int* dm = py.dims[lev - 1];
-        float lb = INFINITY;
-        if (cx < dm[0] && cy < dm[1] && cz < dm[2]) {
-          const uint64_t id = py.off[lev - 1] + ((uint64_t)cz * dm[1] + cy) * dm[0] + cx;
-          const float4 lo = *reinterpret_cast<const float4*>(aabb + 8 * id);      // lo.x lo.y lo.z hi.x
-          const float4 hi = *reinterpret_cast<const float4*>(aabb + 8 * id + 4);  // hi.y hi.z 0 0
-          if (lo.x <= lo.w) {
-            const float px = fminf(fmaxf(qx, lo.x), lo.w), pyc = fminf(fmaxf(qy, lo.y), hi.x),
-                        pz = fminf(fmaxf(qz, lo.z), hi.y);
-            lb = l2_simple3(qx, qy, qz, px, pyc, pz);
-          }
-        }
+        const int4 dm = s_pyr[lev - 1];   // {dims x, y, z, node offset}
+        const bool in = cx < dm.x && cy < dm.y && cz < dm.z;
+        const uint32_t id = (uint32_t)dm.w + (in ? (uint32_t)((cz * dm.y + cy) * dm.x + cx) : 0u);   // < 2^32 nodes
+        const float4 lo = *reinterpret_cast<const float4*>(aabb + 8 * (size_t)id);      // lo.x lo.y lo.z hi.x
+        const float4 hi = *reinterpret_cast<const float4*>(aabb + 8 * (size_t)id + 4);  // hi.y hi.z 0 0
+        const float px = fminf(fmaxf(qx, lo.x), lo.w), pyc = fminf(fmaxf(qy, lo.y), hi.x),
+                    pz = fminf(fmaxf(qz, lo.z), hi.y);
+        const float lbv = l2_simple3(qx, qy, qz, px, pyc, pz);
+        const float lb = (in && lo.x <= lo.w) ? lbv : INFINITY;   // empty nodes have an inverted box
         s_lb[wave][lev][lane] = lb;
         const unsigned long long m = __ballot(lb <= best_d);
         if (lane == 0) { s_mask[wave][lev] = m; s_node[wave][lev][0] = nx; s_node[wave][lev][1] = ny; s_node[wave][lev][2] = nz; }
@@ -802,17 +807,19 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
         // and roughly half the points of a block that a plane crosses never leave HBM.
         uint32_t rs = 0, rn = 0;
         float sl = INFINITY;   // lanes 0..7: exact lower bound of the lane's sub-block (inf: empty)
-        if (lane < 8) {
+        {
+          // (all 64 lanes load, lanes 8.. re-read record 7: no branch around the loads, one round trip)
           const uint64_t blk = ((uint64_t)nz * g.bdims[1] + ny) * g.bdims[0] + nx;
-          const float4 lo = *reinterpret_cast<const float4*>(sub_aabb + 8 * (blk * 8 + lane));      // lo.xyz hi.x
-          const float4 hi = *reinterpret_cast<const float4*>(sub_aabb + 8 * (blk * 8 + lane) + 4);  // hi.y hi.z start count
+          const int rl = lane < 8 ? lane : 7;
+          const float4 lo = *reinterpret_cast<const float4*>(sub_aabb + 8 * (blk * 8 + rl));      // lo.xyz hi.x
+          const float4 hi = *reinterpret_cast<const float4*>(sub_aabb + 8 * (blk * 8 + rl) + 4);  // hi.y hi.z start count
           const uint32_t cnt = __float_as_uint(hi.w);
-          if (cnt) {
-            const float px = fminf(fmaxf(qx, lo.x), lo.w), pyc = fminf(fmaxf(qy, lo.y), hi.x),
-                        pz = fminf(fmaxf(qz, lo.z), hi.y);
-            sl = l2_simple3(qx, qy, qz, px, pyc, pz);
-            rs = __float_as_uint(hi.z); rn = cnt;
-          }
+          const float px = fminf(fmaxf(qx, lo.x), lo.w), pyc = fminf(fmaxf(qy, lo.y), hi.x),
+                      pz = fminf(fmaxf(qz, lo.z), hi.y);
+          const float slv = l2_simple3(qx, qy, qz, px, pyc, pz);
+          const bool use = lane < 8 && cnt != 0;
+          sl = use ? slv : INFINITY;
+          rs = use ? __float_as_uint(hi.z) : 0u; rn = use ? cnt : 0u;
         }
         // Sub-blocks NEAREST FIRST, the best distance updated after each: the first one usually brings the bound down
         // to the query's true distance and the other seven fail their test -- scanning all survivors of the test

@@ -563,6 +563,10 @@ pcd_status pcd_profile_reset(void);
 /* fills up to cap entries, returns the number of distinct kernels in *count (syncs the device) */
 pcd_status pcd_profile_get(pcd_kernel_time* entries, int cap, int* count);
 
+/* Not declared here on purpose: the tuning hooks bench.py / tools use (pcd_nn_set_tuning, pcd_nn_set_search,
+ * pcd_nn_set_brick_shift, pcd_nn_set_bookkeeping) set PROCESS-GLOBAL state -- they are for experiments on one handle at
+ * a time, not part of the ABI, and the thread-safety statement at the top of this header does not cover them. */
+
 /* statistics of the last pcd_nn_query*(…, PCD_NN_AUTO) call on this handle */
 typedef struct {
   uint64_t queries;

@@ -66,7 +66,9 @@ def test_filter_tracks_against_oracle(gpu, oracle):
         s[k] = s[k][keep]
     ob = oracle.BA(**s)
     sq, depth = ob.observation_errors()
-    for max_err in (4.0, 1.0, 0.0):
+    fin = np.sqrt(sq[sq < 1e300])
+    q70, q30 = float(np.quantile(fin, 0.7)), float(np.quantile(fin, 0.3))   # the poses are perturbed: errors of tens of px
+    for max_err in (q70, q30, 0.0):
         exp = oracle.filter_tracks(sq, depth, s["obs_point"], 4000, max_err)
         ba = gpu.BA(**s)
         got = ba.filter_tracks(max_err)
@@ -76,5 +78,7 @@ def test_filter_tracks_against_oracle(gpu, oracle):
             assert got[k] == exp[k], (max_err, k, got[k], exp[k])
         np.testing.assert_allclose(got["point_error"], exp["point_error"], rtol=1e-12, atol=1e-12)
         assert abs(got["mean_reproj_error"] - exp["mean_reproj_error"]) <= 1e-12 * max(1.0, exp["mean_reproj_error"])
-        assert 0 < exp["point_delete"].sum() < 4000 and exp["num_negative_depth"] > 0
+        assert exp["num_negative_depth"] > 0
+        if max_err == q70:
+            assert 0 < exp["point_delete"].sum() < 4000 and 0 < exp["obs_erase"].sum() < len(exp["obs_erase"])
         ba.close()

@@ -13,7 +13,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $R/b
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_write -- python3 $R/bench.py $ARGS > $out/bench_pmc2.json 2> $out/pmc2.err || exit 1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $out/pmc_sq -- python3 $R/bench.py $ARGS > $out/bench_pmc3.json 2> $out/pmc3.err || exit 1
 cd $R
-python3 tools/prof_summary.py $out k_nn_ k_ba_ k_brick k_associate k_prepare k_finalize k_query > $out/summary.txt 2>&1
+python3 tools/prof_summary.py $out k_nn_ k_ba_ k_bk_ k_fb_ k_brick k_associate k_prepare k_finalize k_query > $out/summary.txt 2>&1
 python3 tools/make_traffic.py $out 10000000 1000000 > $out/traffic.log 2>&1
 cp profiles/traffic.json $out/traffic.json
 find $out -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
