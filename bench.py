@@ -424,6 +424,37 @@ def main():
                                           queries_per_sec=20_000 / t_a)
             ca.close()
 
+    # ---- config 5 (SIFT, the one MFMA use): one block of the exhaustive matcher = 50 images x 8192 descriptors,
+    # 1225 pairs through the batched entry (SiftFeatureMatcher::Match(image_pairs), feature/matching.cc:798) ----
+    if not a.no_extras and rank == 0:
+        n_img, n_desc = 50, 8192
+        rng = np.random.default_rng(0)
+        f = rng.random((n_desc, 128), dtype=np.float32) ** 2
+        f /= np.linalg.norm(f, axis=1, keepdims=True)
+        base = np.clip(np.round(512 * f), 0, 255).astype(np.int32)
+        arena = np.concatenate([np.clip(base[rng.permutation(n_desc)] + rng.integers(-5, 6, (n_desc, 128)), 0, 255).astype(np.uint8)
+                                for _ in range(n_img)], axis=0)
+        first = np.arange(n_img + 1, dtype=np.uint64) * np.uint64(n_desc)
+        pairs = np.array([(i, j) for i in range(n_img) for j in range(i + 1, n_img)], np.uint32)
+        off = np.arange(len(pairs), dtype=np.uint64) * np.uint64(n_desc)
+        d_arena = torch.from_numpy(arena).to(dev)
+        d_m = torch.empty(len(pairs) * n_desc, 2, dtype=torch.int32, device=dev)
+        d_c = torch.empty(len(pairs), dtype=torch.int32, device=dev)
+        for _ in range(2):
+            pcdhip.sift_match_batch_device(d_arena, first, pairs, d_m, off, d_c, device=local_rank, stream=stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            pcdhip.sift_match_batch_device(d_arena, first, pairs, d_m, off, d_c, device=local_rank, stream=stream)
+        torch.cuda.synchronize()
+        t_sift = (time.perf_counter() - t0) / 3
+        useful = 2.0 * 128 * n_desc * n_desc * len(pairs) / t_sift / 1e12
+        extras["sift_block"] = dict(workload=f"{n_img} images x {n_desc} descriptors, {len(pairs)} pairs (one exhaustive-matcher block)",
+                                    ms=t_sift * 1e3, us_per_pair=t_sift / len(pairs) * 1e6, pairs_per_sec=len(pairs) / t_sift,
+                                    useful_TOPs=useful, useful_frac_of_dense_i8_peak=useful / 5000.0,
+                                    matches=int(d_c.sum().item()), config5_450_images_s=101025 * t_sift / len(pairs))
+        del d_arena, d_m, d_c
+
     # ---- the Ceres route end to end (shim/ceres_adapter.h): PrepareForEvaluation with Jacobians + one sweep of every
     # block's Evaluate, PCIe included -- what a colmap user's ceres::Solve sees per evaluation (C++ harness, run as a
     # child process; config B = Smith Hall 450-like, M = the metric workload) ----
@@ -492,7 +523,8 @@ def main():
                          "algorithmic_bytes": alg_bytes, "bytes_per_staged_point": POINT_BYTES,
                          "frac_16B_records": rec_achieved / HBM_PEAK_GBS, "launch_ms": brick_ms,
                          "staged_points": staged, "brick_groups": st["brick_groups"],
-                         "fallback_queries": st["fallback_queries"], "pair_evals": st["pair_evals"],
+                         "fallback_queries": st["fallback_queries"], "fallback_points": st["fallback_points"],
+                         "pair_evals": st["pair_evals"],
                          "compulsory_bytes": 12 * a.cloud + PER_QUERY_BYTES * Q,
                          "note": "the kernel is VALU-bound, not HBM-bound (DESIGN.md section 5): frac is SURVEY 8d's "
                                  "algorithmic figure, hbm_frac the measured HBM share; compare kernels by launch_ms"},
