@@ -7,13 +7,11 @@
 //   sorted [m] float4 {x,y,z,bits(global_idx)}  finite rows in cell-sorted order (x fastest):
 //              one 16-B record per lane per load; a row of cells along x is one contiguous range
 //   cell_start [ncells+1] uint32    exclusive prefix of per-cell counts
-//   blk_aabb [nodes][8] float       tight bounds {lo.xyz, hi.xyz, 0, 0}: every 4x4x4-cell block (level 0)
-//                                   followed by the coarser pyramid levels (4x4x4 children each)
-//   sub_aabb [nblocks][8][8] float  the 8 sub-blocks of 2x2x2 cells of every block: {lo.xyz, hi.xyz, bits(first
-//                                   point), bits(count)}.  A sub-block is an x-range of 2 cells of ONE quad row, i.e.
-//                                   one contiguous point range; sub = quad_row_in_block * 2 + x_half, so the two
-//                                   halves of a row are adjacent records and adjacent ranges.  The exact fallback
-//                                   prunes and addresses its leaf scans with these (no cell_start round trip)
+//   blk_aabb [nodes][8] float       the AABB pyramid of the exact fallback.  Level 0 = LEAVES: every sub-block of
+//                                   2x2x2 cells -- an x-range of 2 cells of ONE quad row, i.e. one contiguous point
+//                                   range -- as {lo.xyz, hi.x | hi.y, hi.z, bits(first point), bits(count)}; level
+//                                   k+1 = 4x4x4 nodes of level k as {lo.xyz, hi.xyz, 0, 0}; the top level is one node.
+//                                   An expansion tests 64 children with the exact float bound; a leaf is scanned.
 #pragma once
 #include "common.h"
 
@@ -31,8 +29,9 @@ struct GridParams {
   float slack;    // metres: bound on binning rounding, see nn.hip
 };
 
-// 64-ary AABB pyramid over the blocks: level 0 = blocks, level k+1 = 4x4x4 nodes of level k,
-// top level = one node.  All levels live in blk_aabb (8 floats per node) at off[level].
+// 64-ary AABB pyramid: level 0 = leaves (2x2x2-cell sub-blocks), level k+1 = 4x4x4 nodes of level k, up to the first
+// level with at most 64 nodes (level nlev-2); level nlev-1 is a VIRTUAL top whose children are all nodes of level
+// nlev-2, one per lane.  The real levels live in blk_aabb (8 floats per node) at off[level].
 constexpr int kMaxPyrLevels = 10;
 struct PyramidParams {
   int nlev;                       // >= 2
@@ -72,7 +71,7 @@ struct pcd_cloud {
   uint64_t g2l_n = 0;
   pcd::DevBuf<float4> pts4, nrm4, sorted;
   pcd::DevBuf<uint32_t> cell_start;
-  pcd::DevBuf<float> blk_aabb, sub_aabb;
+  pcd::DevBuf<float> blk_aabb;
   pcd::GridParams grid{};
   pcd::PyramidParams pyr{};
   uint64_t ncells = 0, nblocks = 0, occupied = 0;

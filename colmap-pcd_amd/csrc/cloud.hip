@@ -138,79 +138,38 @@ __global__ void k_gather_sorted(const float4* __restrict__ pts4, const uint32_t*
   sorted[i] = p;
 }
 
-// one wavefront per 4x4x4-cell block: tight AABB of its points (2x2 quad rows of 4 x-cells, each contiguous)
-__global__ void k_block_aabb(const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, GridParams g,
-                             uint64_t nblocks, float* __restrict__ aabb) {
+// Pyramid level 0 = LEAVES: every sub-block of 2x2x2 cells (half a quad row of two x-cells: ONE contiguous point
+// range) with its tight box and its range, {lo.xyz, hi.x | hi.y, hi.z, bits(first point), bits(count)}.  One wavefront
+// per leaf.  (Round 2 had 4x4x4-cell blocks as level 0 with 8 sub-block records each: a far query then paid one walk
+// step per BLOCK of the shell between its true distance and the blocks' looser bounds; with the sub-blocks as the
+// children of a 64-ary node one step tests 64 of them.)
+__global__ void k_leaf_aabb(const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, GridParams g,
+                            int sdx, int sdy, int sdz, float* __restrict__ aabb) {
   const int lane = threadIdx.x & 63;
-  uint64_t blk = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-  if (blk >= nblocks) return;
-  int bx = (int)(blk % g.bdims[0]);
-  int by = (int)((blk / g.bdims[0]) % g.bdims[1]);
-  int bz = (int)(blk / ((uint64_t)g.bdims[0] * g.bdims[1]));
+  const uint64_t id = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+  if (id >= (uint64_t)sdx * sdy * sdz) return;
+  const int sx = (int)(id % sdx), sy = (int)((id / sdx) % sdy), sz = (int)(id / ((uint64_t)sdx * sdy));
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int r = 0; r < 4; ++r) {
-    int yq = by * 2 + (r & 1), zq = bz * 2 + (r >> 1);
-    if (yq >= g.qdims[0] || zq >= g.qdims[1]) continue;
-    int cx0 = bx * kBlockCells, cx1 = min(cx0 + kBlockCells, g.dims[0]);
-    uint64_t rowbase = quad_row_base(g, yq, zq);
-    uint32_t s = cell_start[rowbase + 4 * cx0], e = cell_start[rowbase + 4 * cx1];
-    for (uint32_t i = s + lane; i < e; i += 64) {
-      float4 p = sorted[i];
-      lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
-      lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
-      lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
-    }
+  const int cx0 = min(2 * sx, g.dims[0]), cx1 = min(cx0 + 2, g.dims[0]);
+  const uint64_t rowbase = quad_row_base(g, sy, sz);
+  const uint32_t s = cell_start[rowbase + 4 * cx0], e = cell_start[rowbase + 4 * cx1];
+  for (uint32_t i = s + lane; i < e; i += 64) {
+    const float4 p = sorted[i];
+    lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+    lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+    lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
   }
-  for (int off = 32; off > 0; off >>= 1)
-    for (int d = 0; d < 3; ++d) {
-      lo[d] = fminf(lo[d], __shfl_xor(lo[d], off));
-      hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off));
-    }
-  if (lane == 0) {
-    float* o = aabb + 8 * blk;
-    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2];
-    o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
-    o[6] = 0.f; o[7] = 0.f;
-  }
-}
-
-// one wavefront per block: tight AABB + point range of each of its 8 sub-blocks (2x2x2 cells; cloud.h)
-__global__ void k_sub_aabb(const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, GridParams g,
-                           uint64_t nblocks, float* __restrict__ sub) {
-  const int lane = threadIdx.x & 63;
-  uint64_t blk = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-  if (blk >= nblocks) return;
-  int bx = (int)(blk % g.bdims[0]);
-  int by = (int)((blk / g.bdims[0]) % g.bdims[1]);
-  int bz = (int)(blk / ((uint64_t)g.bdims[0] * g.bdims[1]));
-  for (int sb = 0; sb < 8; ++sb) {
-    const int r = sb >> 1, xh = sb & 1;
-    const int yq = by * 2 + (r & 1), zq = bz * 2 + (r >> 1);
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    uint32_t s = 0, e = 0;
-    if (yq < g.qdims[0] && zq < g.qdims[1]) {
-      const int cx0 = min(bx * kBlockCells + 2 * xh, g.dims[0]), cx1 = min(cx0 + 2, g.dims[0]);
-      const uint64_t rowbase = quad_row_base(g, yq, zq);
-      s = cell_start[rowbase + 4 * cx0];
-      e = cell_start[rowbase + 4 * cx1];
-      for (uint32_t i = s + lane; i < e; i += 64) {
-        const float4 p = sorted[i];
-        lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
-        lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
-        lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
-      }
-    }
+  if (s != e)
     for (int off = 32; off > 0; off >>= 1)
       for (int d = 0; d < 3; ++d) {
         lo[d] = fminf(lo[d], __shfl_xor(lo[d], off));
         hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off));
       }
-    if (lane == 0) {
-      float* o = sub + 8 * (blk * 8 + sb);
-      o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2];
-      o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
-      o[6] = __uint_as_float(s); o[7] = __uint_as_float(e - s);
-    }
+  if (lane == 0) {
+    float* o = aabb + 8 * id;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2];
+    o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
+    o[6] = __uint_as_float(s); o[7] = __uint_as_float(e - s);
   }
 }
 
@@ -373,28 +332,35 @@ static pcd_status build_grid(pcd_cloud* c, float user_h, hipStream_t s) {
     PCD_HIP_TRY(hipStreamSynchronize(s));
   }
 
-  // --- tight block bounds + coarser pyramid levels ---
+  // --- leaves (2x2x2-cell sub-blocks: tight box + point range) + coarser pyramid levels ---
   PyramidParams& py = c->pyr;
   py.nlev = 1;
-  for (int d = 0; d < 3; ++d) py.dims[0][d] = g.bdims[d];
+  py.dims[0][0] = (g.dims[0] + 1) / 2; py.dims[0][1] = g.qdims[0]; py.dims[0][2] = g.qdims[1];
   py.off[0] = 0;
-  uint64_t total_nodes = c->nblocks;
-  while (py.nlev < kMaxPyrLevels) {
+  const uint64_t nleaves = (uint64_t)py.dims[0][0] * py.dims[0][1] * py.dims[0][2];
+  uint64_t total_nodes = nleaves;
+  // real levels until one has at most 64 nodes; above it sits a VIRTUAL top whose children are ALL nodes of that level,
+  // one per lane (k_nn_fallback): for workload M's grid that is 5 x 2 x 5 = 50 nodes -- the walk starts there instead of
+  // expanding a root of 1 and a level of 4 nodes first (two expansions and two pops less per query)
+  while (py.nlev < kMaxPyrLevels - 1) {
     const int* pd = py.dims[py.nlev - 1];
-    const bool single = pd[0] == 1 && pd[1] == 1 && pd[2] == 1;
-    if (single && py.nlev >= 2) break;
+    if ((uint64_t)pd[0] * pd[1] * pd[2] <= 64) break;
     for (int d = 0; d < 3; ++d) py.dims[py.nlev][d] = (pd[d] + 3) / 4;
     py.off[py.nlev] = (uint32_t)total_nodes;
     total_nodes += (uint64_t)py.dims[py.nlev][0] * py.dims[py.nlev][1] * py.dims[py.nlev][2];
     py.nlev++;
   }
+  if ((uint64_t)py.dims[py.nlev - 1][0] * py.dims[py.nlev - 1][1] * py.dims[py.nlev - 1][2] > 64) {
+    set_error("grid too large for %d pyramid levels", kMaxPyrLevels);
+    return PCD_ERR_UNSUPPORTED;
+  }
+  py.dims[py.nlev][0] = py.dims[py.nlev][1] = py.dims[py.nlev][2] = 1;   // the virtual top
+  py.off[py.nlev] = (uint32_t)total_nodes;
+  py.nlev++;
   PCD_TRY(c->blk_aabb.reserve(8 * total_nodes));
-  hipLaunchKernelGGL(k_block_aabb, dim3(div_up(c->nblocks * 64, 256)), dim3(256), 0, s, c->sorted.p,
-                     c->cell_start.p, g, c->nblocks, c->blk_aabb.p);
-  PCD_TRY(c->sub_aabb.reserve(64 * std::max<uint64_t>(c->nblocks, 1)));
-  hipLaunchKernelGGL(k_sub_aabb, dim3(div_up(c->nblocks * 64, 256)), dim3(256), 0, s, c->sorted.p,
-                     c->cell_start.p, g, c->nblocks, c->sub_aabb.p);
-  for (int l = 1; l < py.nlev; ++l) {
+  hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(nleaves * 64, 256)), dim3(256), 0, s, c->sorted.p, c->cell_start.p, g,
+                     py.dims[0][0], py.dims[0][1], py.dims[0][2], c->blk_aabb.p);
+  for (int l = 1; l < py.nlev - 1; ++l) {   // (the last level is the virtual top: no boxes)
     const int* cd = py.dims[l - 1];
     const int* pd = py.dims[l];
     const uint64_t np = (uint64_t)pd[0] * pd[1] * pd[2];

@@ -719,7 +719,6 @@ template <int FUSED>
 __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams py, const float4* __restrict__ sorted,
                                                       const uint32_t* __restrict__ cell_start,
                                                       const float* __restrict__ aabb,
-                                                      const float* __restrict__ sub_aabb,
                                                       const float4* __restrict__ qf4,
                                                       const uint32_t* __restrict__ list,  // NULL: queries 0..count-1
                                                       const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
@@ -729,6 +728,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
   __shared__ unsigned long long s_mask[4][kMaxPyrLevels];
   __shared__ int s_node[4][kMaxPyrLevels][3];
   __shared__ int4 s_pyr[kMaxPyrLevels];   // per level {dims x, y, z, node offset}
+  __shared__ uint32_t s_rs[4][64], s_rn[4][64];   // point range of the 64 leaves under the current level-1 node
   if (threadIdx.x < (unsigned)kMaxPyrLevels)
     s_pyr[threadIdx.x] = make_int4(py.dims[threadIdx.x][0], py.dims[threadIdx.x][1], py.dims[threadIdx.x][2], (int)py.off[threadIdx.x]);
   __syncthreads();
@@ -738,6 +738,9 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
   const uint32_t nwaves = gridDim.x * 4;
   const int top = py.nlev - 1;  // >= 1
   const int ci = lane & 3, cj = (lane >> 2) & 3, ck = lane >> 4;
+  // the lane's child of the virtual top: flat index over the dimensions of level top - 1 (at most 64 nodes)
+  const int tdx = py.dims[top - 1][0], tdy = py.dims[top - 1][1];
+  const int tcx = lane % tdx, tcy = (lane / tdx) % tdy, tcz = lane / (tdx * tdy);   // tcz >= dims z: no such node
   unsigned long long st_pts = 0, st_q = 0;
   for (uint32_t e = blockIdx.x * 4 + wave; e < count; e += nwaves) {
     const uint32_t qi = list ? list[e] : e;
@@ -765,15 +768,18 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
     int lev = top;
     int nx = 0, ny = 0, nz = 0;
     bool expand = true;
+    uint32_t q_steps = 0, q_leaves = 0;
     while (true) {
+      ++q_steps;
       if (expand) {
         // children of node (nx,ny,nz) of level `lev` live on level lev-1.  ONE memory round trip per expansion: the
         // level's dimensions and offset come from LDS (as kernel arguments indexed by `lev` they were four dependent
         // scalar loads), the child's two 16-byte loads are unconditional on a clamped index and the bound is selected
         // afterwards (under `if (non-empty)` the compiler split them into a first pair of dwords, the test, and a
         // second, dependent pair of loads): the walk is a chain of such steps and its latency is the kernel's time.
-        const int cx = 4 * nx + ci, cy = 4 * ny + cj, cz = 4 * nz + ck;
         const int4 dm = s_pyr[lev - 1];   // {dims x, y, z, node offset}
+        // (the virtual top's children are ALL nodes of the level below, lane = flat node index)
+        const int cx = lev == top ? tcx : 4 * nx + ci, cy = lev == top ? tcy : 4 * ny + cj, cz = lev == top ? tcz : 4 * nz + ck;
         const bool in = cx < dm.x && cy < dm.y && cz < dm.z;
         const uint32_t id = (uint32_t)dm.w + (in ? (uint32_t)((cz * dm.y + cy) * dm.x + cx) : 0u);   // < 2^32 nodes
         const float4 lo = *reinterpret_cast<const float4*>(aabb + 8 * (size_t)id);      // lo.x lo.y lo.z hi.x
@@ -783,6 +789,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
         const float lbv = l2_simple3(qx, qy, qz, px, pyc, pz);
         const float lb = (in && lo.x <= lo.w) ? lbv : INFINITY;   // empty nodes have an inverted box
         s_lb[wave][lev][lane] = lb;
+        if (lev == 1) { s_rs[wave][lane] = __float_as_uint(hi.z); s_rn[wave][lane] = __float_as_uint(hi.w); }   // leaves carry their range
         const unsigned long long m = __ballot(lb <= best_d);
         if (lane == 0) { s_mask[wave][lev] = m; s_node[wave][lev][0] = nx; s_node[wave][lev][1] = ny; s_node[wave][lev][2] = nz; }
         expand = false;
@@ -797,55 +804,70 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
       const int sl = wave_argmin_u32(__float_as_uint(lb), m);  // nearest remaining child (lb >= 0: bit order)
       m &= ~(1ull << sl);
       if (lane == 0) s_mask[wave][lev] = m;
-      nx = 4 * s_node[wave][lev][0] + (sl & 3);
-      ny = 4 * s_node[wave][lev][1] + ((sl >> 2) & 3);
-      nz = 4 * s_node[wave][lev][2] + (sl >> 4);
+      if (lev == top) {
+        nx = __builtin_amdgcn_readlane(tcx, sl); ny = __builtin_amdgcn_readlane(tcy, sl); nz = __builtin_amdgcn_readlane(tcz, sl);
+      } else {
+        nx = 4 * s_node[wave][lev][0] + (sl & 3);
+        ny = 4 * s_node[wave][lev][1] + ((sl >> 2) & 3);
+        nz = 4 * s_node[wave][lev][2] + (sl >> 4);
+      }
       if (lev == 1) {
-        // (nx,ny,nz) is a block.  Its 8 sub-blocks of 2x2x2 cells are contiguous point ranges with their own tight
-        // boxes (cloud.h sub_aabb: {lo, hi, first point, count}, one 32-B record each): lanes 0..7 test them with
-        // the same exact bound as the pyramid nodes and only the survivors are scanned -- no cell_start round trip,
-        // and roughly half the points of a block that a plane crosses never leave HBM.
-        uint32_t rs = 0, rn = 0;
-        float sl = INFINITY;   // lanes 0..7: exact lower bound of the lane's sub-block (inf: empty)
-        {
-          // (all 64 lanes load, lanes 8.. re-read record 7: no branch around the loads, one round trip)
-          const uint64_t blk = ((uint64_t)nz * g.bdims[1] + ny) * g.bdims[0] + nx;
-          const int rl = lane < 8 ? lane : 7;
-          const float4 lo = *reinterpret_cast<const float4*>(sub_aabb + 8 * (blk * 8 + rl));      // lo.xyz hi.x
-          const float4 hi = *reinterpret_cast<const float4*>(sub_aabb + 8 * (blk * 8 + rl) + 4);  // hi.y hi.z start count
-          const uint32_t cnt = __float_as_uint(hi.w);
-          const float px = fminf(fmaxf(qx, lo.x), lo.w), pyc = fminf(fmaxf(qy, lo.y), hi.x),
-                      pz = fminf(fmaxf(qz, lo.z), hi.y);
-          const float slv = l2_simple3(qx, qy, qz, px, pyc, pz);
-          const bool use = lane < 8 && cnt != 0;
-          sl = use ? slv : INFINITY;
-          rs = use ? __float_as_uint(hi.z) : 0u; rn = use ? cnt : 0u;
-        }
-        // Sub-blocks NEAREST FIRST, the best distance updated after each: the first one usually brings the bound down
-        // to the query's true distance and the other seven fail their test -- scanning all survivors of the test
-        // against the bound the block was ENTERED with (round 2) read ~1 760 points per query, most of them in the
-        // first block of a walk, whose bound is still infinite.
-        while (true) {
-          const unsigned long long mm = __ballot(sl <= best_d);
-          if (mm == 0) break;
-          const int r = wave_argmin_u32(__float_as_uint(sl), mm);   // wave-uniform
-          const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)rs, r), n0 = (uint32_t)__builtin_amdgcn_readlane((int)rn, r);
-          if (lane == r) sl = INFINITY;
-          for (uint32_t base = 0; base < n0; base += 64 * kFbLoads) {
-            float4 p[kFbLoads];
+        // the child is a LEAF (cloud.h: a sub-block of 2x2x2 cells, one contiguous point range with a tight box): scan
+        // it, 256 points per step with the four loads of a step issued back to back (clamped indices, no branches
+        // around the loads: a re-read is harmless), then tighten the bound -- the other leaves of the node are tested
+        // against it when their turn comes (nearest first)
+        const uint32_t s0 = s_rs[wave][sl], n0 = s_rn[wave][sl];
+        for (uint32_t base = 0; base < n0; base += 64 * kFbLoads) {
+          float4 p[kFbLoads];
 #pragma unroll
-            for (int k = 0; k < kFbLoads; ++k) {   // clamped indices, no branches around the loads: a re-read is harmless
-              const uint32_t gi = base + k * 64 + lane;
-              p[k] = sorted[s0 + (gi < n0 ? gi : n0 - 1)];
-            }
-#pragma unroll
-            for (int k = 0; k < kFbLoads; ++k) {
-              const float d = l2_simple3(qx, qy, qz, p[k].x, p[k].y, p[k].z);
-              const uint64_t key = make_key(d, __float_as_uint(p[k].w));
-              lane_best = key < lane_best ? key : lane_best;
-            }
+          for (int k = 0; k < kFbLoads; ++k) {
+            const uint32_t gi = base + k * 64 + lane;
+            p[k] = sorted[s0 + (gi < n0 ? gi : n0 - 1)];
           }
-          st_pts += n0;
+#pragma unroll
+          for (int k = 0; k < kFbLoads; ++k) {
+            const float d = l2_simple3(qx, qy, qz, p[k].x, p[k].y, p[k].z);
+            const uint64_t key = make_key(d, __float_as_uint(p[k].w));
+            lane_best = key < lane_best ? key : lane_best;
+          }
+        }
+        st_pts += n0;
+        ++q_leaves;
+        best = wave_min_u64(lane_best);
+        best_d = __uint_as_float((uint32_t)(best >> 32));
+        // The node's OTHER leaves that still pass the tightened bound: all of them in one batch -- two leaves' loads in
+        // flight at a time, no reduction in between.  They would each be scanned anyway (a leaf on a tilted surface has a
+        // fat box: a far query at distance d finds ~d / 0.1 m leaves whose box is nearer than d although none of their
+        // points is -- 129 leaf scans in the longest walk of workload M, one walk step each before); the rare leaf that
+        // a batch neighbour would have ruled out costs one load.
+        unsigned long long mb = m & __ballot(lb <= best_d);
+        if (mb) {
+          m &= ~mb;
+          if (lane == 0) s_mask[wave][lev] = m;
+          while (mb) {
+            const int r0 = __ffsll((long long)mb) - 1;
+            mb &= mb - 1;
+            const int r1 = mb ? __ffsll((long long)mb) - 1 : r0;
+            mb &= mb - 1;   // (0 stays 0)
+            const uint32_t a0 = s_rs[wave][r0], c0 = s_rn[wave][r0], a1 = s_rs[wave][r1], c1 = r1 != r0 ? s_rn[wave][r1] : 0u;
+            const uint32_t cmax = c0 > c1 ? c0 : c1;
+            for (uint32_t base = 0; base < cmax; base += 128) {
+              float4 p[4];
+              const uint32_t g0 = base + lane, g1 = base + 64 + lane;
+              p[0] = sorted[a0 + (g0 < c0 ? g0 : c0 - 1)];
+              p[1] = sorted[a0 + (g1 < c0 ? g1 : c0 - 1)];
+              p[2] = sorted[a1 + (c1 ? (g0 < c1 ? g0 : c1 - 1) : 0u)];
+              p[3] = sorted[a1 + (c1 ? (g1 < c1 ? g1 : c1 - 1) : 0u)];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float d = l2_simple3(qx, qy, qz, p[k].x, p[k].y, p[k].z);
+                const uint64_t key = make_key(d, __float_as_uint(p[k].w));
+                lane_best = key < lane_best ? key : lane_best;
+              }
+            }
+            st_pts += c0 + c1;
+            q_leaves += r1 != r0 ? 2 : 1;
+          }
           best = wave_min_u64(lane_best);
           best_d = __uint_as_float((uint32_t)(best >> 32));
         }
@@ -856,6 +878,10 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
     }
     if (lane == 0) keys[qi] = FUSED ? finalized_key(best) : best;
     st_q += 1;
+    if (collect_stats && lane == 0) {
+      atomicAdd(&ctr->fb_steps, (unsigned long long)q_steps); atomicAdd(&ctr->fb_leaves, (unsigned long long)q_leaves);
+      atomicMax(&ctr->fb_max_steps, q_steps); atomicMax(&ctr->fb_max_leaves, q_leaves);
+    }
   }
   if (collect_stats && lane == 0) {
     atomicAdd(&ctr->fallback_points, st_pts);
@@ -1040,7 +1066,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
                        &sc->counters.p->fb_count, sc->fb_dense.p, &sc->counters.p->pad[0]);
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), g_fb_max_blocks);
     hipLaunchKernelGGL(k_nn_fallback<0>, dim3(blocks), dim3(256), 0, s, g, c->pyr, c->sorted.p, c->cell_start.p,
-                       c->blk_aabb.p, c->sub_aabb.p, sc->qf4.p, sc->fb_dense.p, &sc->counters.p->pad[0], 0u, d_keys,
+                       c->blk_aabb.p, sc->qf4.p, sc->fb_dense.p, &sc->counters.p->pad[0], 0u, d_keys,
                        sc->counters.p, g_collect_stats, FbFused{nullptr, nullptr, 0, 0.0});
   }
   return PCD_OK;
@@ -1070,11 +1096,11 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
     const FbFused fu{d_q, bound ? bound->d_max_range : nullptr, bound ? bound->count : 0, bound ? bound->fixed : 0.0};
     if (bound)
       hipLaunchKernelGGL(k_nn_fallback<2>, dim3(blocks), dim3(256), 0, s, c->grid, c->pyr, c->sorted.p, c->cell_start.p,
-                         c->blk_aabb.p, c->sub_aabb.p, (const float4*)nullptr, (const uint32_t*)nullptr,
+                         c->blk_aabb.p, (const float4*)nullptr, (const uint32_t*)nullptr,
                          (const uint32_t*)nullptr, (uint32_t)Q, d_keys, sc->counters.p, g_collect_stats, fu);
     else
       hipLaunchKernelGGL(k_nn_fallback<1>, dim3(blocks), dim3(256), 0, s, c->grid, c->pyr, c->sorted.p, c->cell_start.p,
-                         c->blk_aabb.p, c->sub_aabb.p, (const float4*)nullptr, (const uint32_t*)nullptr,
+                         c->blk_aabb.p, (const float4*)nullptr, (const uint32_t*)nullptr,
                          (const uint32_t*)nullptr, (uint32_t)Q, d_keys, sc->counters.p, g_collect_stats, fu);
     PCD_HIP_TRY(hipGetLastError());
     return PCD_OK;
@@ -1109,7 +1135,7 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
       ScopedKernelTimer t("nn_fallback", s);
       const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), g_fb_max_blocks);
       hipLaunchKernelGGL(k_nn_fallback<0>, dim3(blocks), dim3(256), 0, s, c->grid, c->pyr, c->sorted.p, c->cell_start.p,
-                         c->blk_aabb.p, c->sub_aabb.p, sc->qf4.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)Q,
+                         c->blk_aabb.p, sc->qf4.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)Q,
                          d_keys, sc->counters.p, g_collect_stats, FbFused{nullptr, nullptr, 0, 0.0});
     } else if (algo == PCD_NN_AUTO || algo == PCD_NN_GRID) {
       PCD_TRY(run_grid<8>(c, sc, Q, d_keys, s, refine || bound != nullptr));   // incoming keys matter: carry them
@@ -1201,6 +1227,10 @@ pcd_status pcd_nn_last_stats(pcd_cloud* c, pcd_nn_stats* st) {
   st->fallback_queries = h.fallback_queries;
   st->fallback_points = h.fallback_points;
   st->pair_evals = h.pair_evals;
+  if (std::getenv("PCD_FB_STATS"))
+    std::fprintf(stderr, "[pcd] fallback walk: %llu queries, %.1f steps / %.1f leaf scans per query, max %u / %u\n",
+                 (unsigned long long)h.fallback_queries, h.fallback_queries ? (double)h.fb_steps / h.fallback_queries : 0.0,
+                 h.fallback_queries ? (double)h.fb_leaves / h.fallback_queries : 0.0, h.fb_max_steps, h.fb_max_leaves);
   return PCD_OK;
 }
 

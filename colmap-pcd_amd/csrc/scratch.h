@@ -10,6 +10,8 @@ struct NnCounters {
   unsigned int pad[2];   // pad[0] = length of the squeezed fallback list
   unsigned int n_in_grid;     // brick-sorted positions 0 .. n_in_grid-1 are the finite queries inside the grid
   unsigned int st_count[3];   // slots handed out in the stencil stages' output lists (stencil_kernel.h)
+  unsigned int fb_max_steps, fb_max_leaves;   // statistics passes: longest walk of k_nn_fallback (steps, leaf scans)
+  unsigned long long fb_steps, fb_leaves;
 };
 
 struct QueryScratch {
