@@ -160,7 +160,15 @@ def cpu_baseline(xyz, nrm, q, mr, scene, nq, npts):
     t0 = time.time(); obc.evaluate_mt(cores, True); obc.evaluate_mt(cores, False); t_bac = time.time() - t0
     per_point = lambda tnn, tba, n: tnn / nq + tba / n
     v_all = 1.0 / per_point(t_nnc, t_bac, nptc)
-    return dict(value=v_all, unit="queries/s", cores=cores, kind="port",
+    # time the literal FLANN / PCL / Ceres calls if the box has them.  Probe for the headers (nothing is
+    # installed or fetched): absent on every box seen so far, so the timed baseline is the oracle ("port")
+    def have(*names):
+        roots = ("/usr/include", "/usr/local/include", "/opt/rocm/include", "/usr/include/x86_64-linux-gnu")
+        return any(os.path.exists(os.path.join(r, n)) for r in roots for n in names)
+    ref_libs = dict(flann=have("flann/flann.hpp"), pcl=have("pcl/kdtree/kdtree_flann.h", "pcl-1.12/pcl/kdtree/kdtree_flann.h",
+                                                            "pcl-1.10/pcl/kdtree/kdtree_flann.h"),
+                    ceres=have("ceres/ceres.h"), eigen=have("eigen3/Eigen/Core", "Eigen/Core"))
+    return dict(value=v_all, unit="queries/s", cores=cores, kind="port", reference_libs_on_box=ref_libs,
                 host=f"{len(os.sched_getaffinity(0))} logical CPUs visible, cgroup quota {quota if quota else 'none'}, "
                      f"{cores} threads used",
                 sample=f"kd-tree over the full {xyz.shape[0]}-pt cloud (build {t_build:.1f}s, not counted); {nq} queries "

@@ -448,46 +448,48 @@ __global__ __launch_bounds__(1024) void k_bk_slots(const float4* __restrict__ qf
                                                    uint32_t* __restrict__ fb_list, NnCounters* __restrict__ ctr) {
   // few, large workgroups: every workgroup merges its whole LDS histogram into the global one with atomics
   // (1024 workgroups x 2048 buckets = 2 M global atomics made this kernel 145 us)
-  __shared__ uint32_t s_h[kBkMaxCoarse];
+  __shared__ uint32_t s_h[kBkMaxCoarse], s_w[16], s_base;
   for (uint32_t c = threadIdx.x; c < ncoarse; c += 1024) s_h[c] = 0;
   __syncthreads();
-  const uint32_t lane = threadIdx.x & 63;
-  uint32_t fb_base = 0, fb_left = 0;   // this wavefront's chunk of the fallback list
-  for (uint32_t i0 = blockIdx.x * 1024u; i0 < Q; i0 += gridDim.x * 1024u) {
-    const uint32_t i = i0 + threadIdx.x;
-    uint32_t s = kSlotSkip;
-    if (i < Q) {
-      const float4 q = qf4[i];
-      if (q.w != 0.f) {
-        const int cx = cell_coord_raw(q.x, g.origin[0], g.inv_h, g.dims[0]);
-        const int cy = cell_coord_raw(q.y, g.origin[1], g.inv_h, g.dims[1]);
-        const int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
-        const bool in = cx >= 0 && cx < g.dims[0] && cy >= 0 && cy < g.dims[1] && cz >= 0 && cz < g.dims[2];
-        s = kSlotFallback;
-        if (in) {
-          const uint32_t bid = (uint32_t)(((uint64_t)((cz + b.S) / b.B) * b.nb[1] + ((cy + b.S) / b.B)) * b.nb[0] + (cx / b.Bx));
-          if ((brick_slot[bid >> 5] >> (bid & 31u)) & 1u) { s = bid; atomicAdd(&s_h[bid >> shift], 1u); }
+  // rounds of 4 queries per thread: the fallback queries of a round are counted over the WORKGROUP and placed with one
+  // global atomic (a chunk per wavefront, as the brick kernel does it, was one same-address returning atomic per
+  // wavefront of this short kernel: 4096 of them, ~40 of its 54 us)
+  for (uint32_t r0 = blockIdx.x * 4096u; r0 < Q; r0 += gridDim.x * 4096u) {
+    uint32_t sv[4], nfb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t i = r0 + k * 1024u + threadIdx.x;
+      uint32_t s = kSlotSkip;
+      if (i < Q) {
+        const float4 q = qf4[i];
+        if (q.w != 0.f) {
+          const int cx = cell_coord_raw(q.x, g.origin[0], g.inv_h, g.dims[0]);
+          const int cy = cell_coord_raw(q.y, g.origin[1], g.inv_h, g.dims[1]);
+          const int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
+          const bool in = cx >= 0 && cx < g.dims[0] && cy >= 0 && cy < g.dims[1] && cz >= 0 && cz < g.dims[2];
+          s = kSlotFallback;
+          if (in) {
+            const uint32_t bid = (uint32_t)(((uint64_t)((cz + b.S) / b.B) * b.nb[1] + ((cy + b.S) / b.B)) * b.nb[0] + (cx / b.Bx));
+            if ((brick_slot[bid >> 5] >> (bid & 31u)) & 1u) { s = bid; atomicAdd(&s_h[bid >> shift], 1u); }
+          }
         }
+        qslot[i] = s;
       }
-      qslot[i] = s;
+      sv[k] = s;
+      nfb += s == kSlotFallback ? 1u : 0u;
     }
-    const unsigned long long um = __ballot(s == kSlotFallback);
-    if (um) {
-      // up to 64 entries at once: the first fb_left of them finish the current chunk, the others open the next one
-      const uint32_t k = (uint32_t)__popcll(um), rank = (uint32_t)__popcll(um & ((1ull << lane) - 1));
-      const uint32_t old_base = fb_base, old_left = fb_left;
-      uint32_t new_base = 0;
-      if (k > old_left) {
-        uint32_t nb = 0;
-        if (lane == 0) nb = atomicAdd(&ctr->fb_count, 64u);
-        new_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-      }
-      if (s == kSlotFallback) fb_list[rank < old_left ? old_base + rank : new_base + (rank - old_left)] = i;
-      if (k > old_left) { fb_base = new_base + (k - old_left); fb_left = 64u - (k - old_left); }
-      else { fb_base += k; fb_left -= k; }
+    uint32_t total;
+    uint32_t pos = block_excl_scan<16>(nfb, s_w, &total);
+    if (total) {   // workgroup-uniform
+      if (threadIdx.x == 0) s_base = atomicAdd(&ctr->fb_count, total);
+      __syncthreads();
+      pos += s_base;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (sv[k] == kSlotFallback) fb_list[pos++] = r0 + k * 1024u + threadIdx.x;
+      __syncthreads();   // s_base is rewritten in the next round
     }
   }
-  if (lane < fb_left) fb_list[fb_base + lane] = 0xFFFFFFFFu;
   __syncthreads();
   for (uint32_t c = threadIdx.x; c < ncoarse; c += 1024)
     if (s_h[c]) atomicAdd(&chist[c], s_h[c]);
@@ -741,7 +743,8 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
   // the lane's child of the virtual top: flat index over the dimensions of level top - 1 (at most 64 nodes)
   const int tdx = py.dims[top - 1][0], tdy = py.dims[top - 1][1];
   const int tcx = lane % tdx, tcy = (lane / tdx) % tdy, tcz = lane / (tdx * tdy);   // tcz >= dims z: no such node
-  unsigned long long st_pts = 0, st_q = 0;
+  unsigned long long st_pts = 0, st_q = 0, st_steps = 0, st_leaves = 0;
+  uint32_t st_max_steps = 0, st_max_leaves = 0;
   for (uint32_t e = blockIdx.x * 4 + wave; e < count; e += nwaves) {
     const uint32_t qi = list ? list[e] : e;
     float qx, qy, qz;
@@ -878,15 +881,28 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
     }
     if (lane == 0) keys[qi] = FUSED ? finalized_key(best) : best;
     st_q += 1;
-    if (collect_stats && lane == 0) {
-      atomicAdd(&ctr->fb_steps, (unsigned long long)q_steps); atomicAdd(&ctr->fb_leaves, (unsigned long long)q_leaves);
-      atomicMax(&ctr->fb_max_steps, q_steps); atomicMax(&ctr->fb_max_leaves, q_leaves);
-    }
+    st_steps += q_steps; st_leaves += q_leaves;
+    st_max_steps = q_steps > st_max_steps ? q_steps : st_max_steps;
+    st_max_leaves = q_leaves > st_max_leaves ? q_leaves : st_max_leaves;
   }
-  if (collect_stats && lane == 0) {
-    atomicAdd(&ctr->fallback_points, st_pts);
-    atomicAdd(&ctr->pair_evals, st_pts);
-    atomicAdd(&ctr->fallback_queries, st_q);
+  if (collect_stats) {   // (uniform) one set of global atomics per WORKGROUP: same-address atomics serialise at ~10 ns
+    __shared__ unsigned long long s_st[4];   // each, and this grid has 65 k wavefronts (per wavefront: a 3 ms launch)
+    __shared__ unsigned int s_mx[2];
+    if (threadIdx.x < 4) s_st[threadIdx.x] = 0;
+    if (threadIdx.x < 2) s_mx[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane == 0) {
+      atomicAdd(&s_st[0], st_pts); atomicAdd(&s_st[1], st_q); atomicAdd(&s_st[2], st_steps); atomicAdd(&s_st[3], st_leaves);
+      atomicMax(&s_mx[0], st_max_steps); atomicMax(&s_mx[1], st_max_leaves);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_st[1]) {
+      atomicAdd(&ctr->fallback_points, s_st[0]);
+      atomicAdd(&ctr->pair_evals, s_st[0]);
+      atomicAdd(&ctr->fallback_queries, s_st[1]);
+      atomicAdd(&ctr->fb_steps, s_st[2]); atomicAdd(&ctr->fb_leaves, s_st[3]);
+      atomicMax(&ctr->fb_max_steps, s_mx[0]); atomicMax(&ctr->fb_max_leaves, s_mx[1]);
+    }
   }
 }
 
