@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void k_brick_emit(const uint32_t* __restrict__
 // run, every query's result does not.
 constexpr uint32_t kSlotFallback = 0xFFFFFFFEu;   // query: finite, but outside the grid or in a brick without a slot
 constexpr uint32_t kSlotSkip = 0xFFFFFFFFu;       // query: not finite
-constexpr uint32_t kBkMaxCoarse = 4096, kBkMaxFine = 2048, kBkTileQ = 4096;
+constexpr uint32_t kBkMaxCoarse = 4096, kBkMaxFine = 4096, kBkTileQ = 4096;   // 2^24 bricks: every grid of the 2^26-cell budget
 
 // one thread per brick: does the halo region (whole quad rows, as brick_load_meta walks them) hold any point?
 __global__ void k_brick_occupied(GridParams g, BrickParams b, const uint32_t* __restrict__ cell_start,
@@ -567,7 +567,9 @@ __global__ __launch_bounds__(256) void k_bk_emit(const float4* __restrict__ qf4,
                                                  uint32_t* __restrict__ chist, uint32_t* __restrict__ ccur,
                                                  uint4* __restrict__ items, float4* __restrict__ qsorted,
                                                  uint64_t* __restrict__ ksorted, NnCounters* __restrict__ ctr) {
-  __shared__ uint32_t s_cnt[kBkMaxFine], s_off[kBkMaxFine], s_ioff[kBkMaxFine], s_cur[kBkMaxFine], s_w[4];
+  // per fine key: start of its queries / items inside the bucket (kBkMaxFine + 1 entries: the count of key f is
+  // s_off[f + 1] - s_off[f]) and the running rank; 48 KB at 4096 fine keys
+  __shared__ uint32_t s_off[kBkMaxFine + 1], s_ioff[kBkMaxFine + 1], s_cur[kBkMaxFine], s_w[4];
   const uint32_t nfine = 1u << shift, mask = nfine - 1u;
   const uint32_t beg = cstart[blockIdx.x], end = cstart[blockIdx.x + 1];
   // item base = items of all buckets to the left, in bucket order = brick order (the XCD-aware walk of k_nn_brick
@@ -579,19 +581,24 @@ __global__ __launch_bounds__(256) void k_bk_emit(const float4* __restrict__ qf4,
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ctr->nitems = ibase + bitems[blockIdx.x];
   if (threadIdx.x == 0) { chist[blockIdx.x] = 0; ccur[blockIdx.x] = 0; }   // clean for the next batch
   if (beg == end) return;
-  for (uint32_t f = threadIdx.x; f < nfine; f += 256) { s_cnt[f] = 0; s_cur[f] = 0; }
+  for (uint32_t f = threadIdx.x; f < nfine; f += 256) s_cur[f] = 0;
   __syncthreads();
-  for (uint32_t p = beg + threadIdx.x; p < end; p += 256) atomicAdd(&s_cnt[pslot[p] & mask], 1u);
+  for (uint32_t p = beg + threadIdx.x; p < end; p += 256) atomicAdd(&s_cur[pslot[p] & mask], 1u);   // counts
   __syncthreads();
   // exclusive prefixes of the query counts and of the item counts over the bucket's fine keys
   const uint32_t per = (nfine + 255u) / 256u, f0 = threadIdx.x * per;
   {
     uint32_t aq = 0, ai = 0;
-    for (uint32_t f = f0; f < min(f0 + per, nfine); ++f) { aq += s_cnt[f]; ai += (s_cnt[f] + G - 1) / G; }
+    for (uint32_t f = f0; f < min(f0 + per, nfine); ++f) { aq += s_cur[f]; ai += (s_cur[f] + G - 1) / G; }
     uint32_t tq, ti;
     uint32_t bq = block_excl_scan_256(aq, s_w, &tq);
     uint32_t bi = block_excl_scan_256(ai, s_w, &ti);
-    for (uint32_t f = f0; f < min(f0 + per, nfine); ++f) { s_off[f] = bq; s_ioff[f] = bi; bq += s_cnt[f]; bi += (s_cnt[f] + G - 1) / G; }
+    for (uint32_t f = f0; f < min(f0 + per, nfine); ++f) {
+      const uint32_t c = s_cur[f];
+      s_off[f] = bq; s_ioff[f] = bi; bq += c; bi += (c + G - 1) / G;
+      s_cur[f] = 0;                     // becomes the running rank
+    }
+    if (threadIdx.x == 255) { s_off[nfine] = tq; s_ioff[nfine] = ti; }
     __syncthreads();
   }
   for (uint32_t p = beg + threadIdx.x; p < end; p += 256) {
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(256) void k_bk_emit(const float4* __restrict__ qf4,
       const int cx = cell_coord_raw(q.x, g.origin[0], g.inv_h, g.dims[0]);
       const int cy = cell_coord_raw(q.y, g.origin[1], g.inv_h, g.dims[1]);
       const int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
-      const uint32_t left = s_cnt[f] - r;
+      const uint32_t left = s_off[f + 1] - s_off[f] - r;
       items[ibase + s_ioff[f] + r / (uint32_t)G] =
           make_uint4(pos, (uint32_t)(cx / b.Bx), (uint32_t)((cy + b.S) / b.B),
                      (uint32_t)((cz + b.S) / b.B) | ((left < (uint32_t)G ? left : (uint32_t)G) << 28));
@@ -1004,7 +1011,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   PCD_TRY(sc->counters.reserve(1));
   PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
   PCD_TRY(brick_slots(c, sc, b, s));
-  // sort key = brick id: coarse key = id >> shift (at most 4096 buckets), fine key = the low bits (at most 2048)
+  // sort key = brick id: coarse key = id >> shift (at most 4096 buckets), fine key = the low bits (at most 4096)
   uint32_t shift = 8;
   while ((((uint64_t)b.nbricks + (1u << shift) - 1) >> shift) > 2304 && shift < 16) ++shift;
   const uint32_t ncoarse = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)b.nbricks + (1u << shift) - 1) >> shift));

@@ -401,3 +401,21 @@ def test_radix_sort_bookkeeping_still_exact(gpu, oracle):
     finally:
         gpu.set_nn_bookkeeping(0)
     c.close()
+
+
+def test_large_sparse_grid_counting_sort(gpu):
+    """a 40 M-cell grid (5 M bricks: 4096 fine keys per coarse bucket, the widest the counting-sort bookkeeping takes)
+    against the device brute force"""
+    rng = np.random.default_rng(31)
+    n, Q = 200000, 20000
+    xyz = (rng.random((n, 3)) * np.array([60.0, 60.0, 12.0])).astype(np.float32)
+    nrm = np.zeros_like(xyz)
+    nrm[:, 2] = 1.0
+    q = (xyz[rng.integers(0, n, Q)] + rng.normal(0, 0.08, (Q, 3))).astype(np.float32)
+    q[::97] = np.nan
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False, cell_size=0.1)
+    info = c.info()
+    assert int(np.prod(info["dims"])) > 38_000_000, info
+    exp = c.nn(q, gpu.NN_BRUTEFORCE)
+    _check_exact(c.nn(q, gpu.NN_GRID), exp, "40 M-cell grid")
+    c.close()
