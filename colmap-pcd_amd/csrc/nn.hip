@@ -699,10 +699,6 @@ struct FbFused {   // inputs of k_nn_fallback<1 / 2> (the kernel as the only lau
   uint64_t mr_count;
   double fixed_range;
 };
-#ifndef PCD_FB_LOADS
-#define PCD_FB_LOADS 4
-#endif
-constexpr int kFbLoads = PCD_FB_LOADS;   // point loads in flight per lane in a leaf scan step
 
 // scan the point range [s,e): lanes stride over it
 __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, uint32_t s, uint32_t e, float qx,
@@ -737,7 +733,6 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
   __shared__ unsigned long long s_mask[4][kMaxPyrLevels];
   __shared__ int s_node[4][kMaxPyrLevels][3];
   __shared__ int4 s_pyr[kMaxPyrLevels];   // per level {dims x, y, z, node offset}
-  __shared__ uint32_t s_rs[4][64], s_rn[4][64];   // point range of the 64 leaves under the current level-1 node
   if (threadIdx.x < (unsigned)kMaxPyrLevels)
     s_pyr[threadIdx.x] = make_int4(py.dims[threadIdx.x][0], py.dims[threadIdx.x][1], py.dims[threadIdx.x][2], (int)py.off[threadIdx.x]);
   __syncthreads();
@@ -773,119 +768,133 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
                                              fu.q[3 * (size_t)qi], fu.q[3 * (size_t)qi + 1], fu.q[3 * (size_t)qi + 2])
                           : kKeyInit;
     }
-    uint64_t lane_best = best;
+    // The state of the level being iterated lives in REGISTERS (the children's bounds one per lane, the mask of the
+    // children still to visit in an SGPR pair, the node in SGPRs); the LDS arrays are a stack touched only when the walk
+    // descends (push) or comes back (pop).  Before, every iteration went through LDS for the mask and the node -- a
+    // write -> read round trip in the walk's dependent chain, and most iterations are leaves of ONE level-1 node.
+    // The keys are compared as doubles (brick_kernel.h: one v_min_f64 instead of a 64-bit compare + two selects).
+    double lane_best = __builtin_bit_cast(double, best);
     float best_d = __uint_as_float((uint32_t)(best >> 32));
-    int lev = top;
+    int lev = top;                 // the children of node (nx, ny, nz) of level `lev` are being iterated
     int nx = 0, ny = 0, nz = 0;
-    bool expand = true;
+    float cur_lb;
+    unsigned long long cur_m;
+    uint32_t rs = 0, rn = 0;       // lev == 1: the lane's leaf's point range
     uint32_t q_steps = 0, q_leaves = 0;
+    // children of node (nx,ny,nz) of level `lev` live on level lev-1.  ONE memory round trip per expansion: the level's
+    // dimensions and offset come from LDS (as kernel arguments indexed by `lev` they were four dependent scalar loads),
+    // the child's two 16-byte loads are unconditional on a clamped index and the bound is selected afterwards (under
+    // `if (non-empty)` the compiler split them into a first pair of dwords, the test, and a second, dependent pair of
+    // loads): the walk is a chain of such steps and its latency is the kernel's time.
+#define PCD_FB_EXPAND()                                                                                               \
+    {                                                                                                                 \
+      const int4 dm = s_pyr[lev - 1]; /* {dims x, y, z, node offset} */                                               \
+      /* (the virtual top's children are ALL nodes of the level below, lane = flat node index) */                     \
+      const int cx = lev == top ? tcx : 4 * nx + ci, cy = lev == top ? tcy : 4 * ny + cj,                             \
+                cz = lev == top ? tcz : 4 * nz + ck;                                                                  \
+      const bool in = cx < dm.x && cy < dm.y && cz < dm.z;                                                            \
+      const uint32_t id = (uint32_t)dm.w + (in ? (uint32_t)((cz * dm.y + cy) * dm.x + cx) : 0u); /* < 2^32 nodes */   \
+      const float4 lo = *reinterpret_cast<const float4*>(aabb + 8 * (size_t)id);     /* lo.x lo.y lo.z hi.x */        \
+      const float4 hi = *reinterpret_cast<const float4*>(aabb + 8 * (size_t)id + 4); /* hi.y hi.z start count */      \
+      const float px = fminf(fmaxf(qx, lo.x), lo.w), pyc = fminf(fmaxf(qy, lo.y), hi.x),                              \
+                  pz = fminf(fmaxf(qz, lo.z), hi.y);                                                                  \
+      const float lbv = l2_simple3(qx, qy, qz, px, pyc, pz);                                                          \
+      cur_lb = (in && lo.x <= lo.w) ? lbv : INFINITY; /* empty nodes have an inverted box */                          \
+      rs = __float_as_uint(hi.z); rn = __float_as_uint(hi.w); /* leaves carry their range */                          \
+      cur_m = __ballot(cur_lb <= best_d);                                                                             \
+    }
+    PCD_FB_EXPAND();
     while (true) {
       ++q_steps;
-      if (expand) {
-        // children of node (nx,ny,nz) of level `lev` live on level lev-1.  ONE memory round trip per expansion: the
-        // level's dimensions and offset come from LDS (as kernel arguments indexed by `lev` they were four dependent
-        // scalar loads), the child's two 16-byte loads are unconditional on a clamped index and the bound is selected
-        // afterwards (under `if (non-empty)` the compiler split them into a first pair of dwords, the test, and a
-        // second, dependent pair of loads): the walk is a chain of such steps and its latency is the kernel's time.
-        const int4 dm = s_pyr[lev - 1];   // {dims x, y, z, node offset}
-        // (the virtual top's children are ALL nodes of the level below, lane = flat node index)
-        const int cx = lev == top ? tcx : 4 * nx + ci, cy = lev == top ? tcy : 4 * ny + cj, cz = lev == top ? tcz : 4 * nz + ck;
-        const bool in = cx < dm.x && cy < dm.y && cz < dm.z;
-        const uint32_t id = (uint32_t)dm.w + (in ? (uint32_t)((cz * dm.y + cy) * dm.x + cx) : 0u);   // < 2^32 nodes
-        const float4 lo = *reinterpret_cast<const float4*>(aabb + 8 * (size_t)id);      // lo.x lo.y lo.z hi.x
-        const float4 hi = *reinterpret_cast<const float4*>(aabb + 8 * (size_t)id + 4);  // hi.y hi.z 0 0
-        const float px = fminf(fmaxf(qx, lo.x), lo.w), pyc = fminf(fmaxf(qy, lo.y), hi.x),
-                    pz = fminf(fmaxf(qz, lo.z), hi.y);
-        const float lbv = l2_simple3(qx, qy, qz, px, pyc, pz);
-        const float lb = (in && lo.x <= lo.w) ? lbv : INFINITY;   // empty nodes have an inverted box
-        s_lb[wave][lev][lane] = lb;
-        if (lev == 1) { s_rs[wave][lane] = __float_as_uint(hi.z); s_rn[wave][lane] = __float_as_uint(hi.w); }   // leaves carry their range
-        const unsigned long long m = __ballot(lb <= best_d);
-        if (lane == 0) { s_mask[wave][lev] = m; s_node[wave][lev][0] = nx; s_node[wave][lev][1] = ny; s_node[wave][lev][2] = nz; }
-        expand = false;
-      }
-      const float lb = s_lb[wave][lev][lane];
-      unsigned long long m = s_mask[wave][lev] & __ballot(lb <= best_d);
+      unsigned long long m = cur_m & __ballot(cur_lb <= best_d);
       if (m == 0) {
         if (lev == top) break;
-        ++lev;
+        ++lev;   // pop
+        cur_lb = s_lb[wave][lev][lane];
+        const unsigned long long pm = s_mask[wave][lev];
+        cur_m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pm >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)pm);
+        nx = __builtin_amdgcn_readfirstlane(s_node[wave][lev][0]);
+        ny = __builtin_amdgcn_readfirstlane(s_node[wave][lev][1]);
+        nz = __builtin_amdgcn_readfirstlane(s_node[wave][lev][2]);
         continue;
       }
-      const int sl = wave_argmin_u32(__float_as_uint(lb), m);  // nearest remaining child (lb >= 0: bit order)
+      const int sl = wave_argmin_u32(__float_as_uint(cur_lb), m);  // nearest remaining child (lb >= 0: bit order)
       m &= ~(1ull << sl);
-      if (lane == 0) s_mask[wave][lev] = m;
-      if (lev == top) {
-        nx = __builtin_amdgcn_readlane(tcx, sl); ny = __builtin_amdgcn_readlane(tcy, sl); nz = __builtin_amdgcn_readlane(tcz, sl);
-      } else {
-        nx = 4 * s_node[wave][lev][0] + (sl & 3);
-        ny = 4 * s_node[wave][lev][1] + ((sl >> 2) & 3);
-        nz = 4 * s_node[wave][lev][2] + (sl >> 4);
-      }
+      cur_m = m;
       if (lev == 1) {
         // the child is a LEAF (cloud.h: a sub-block of 2x2x2 cells, one contiguous point range with a tight box): scan
-        // it, 256 points per step with the four loads of a step issued back to back (clamped indices, no branches
-        // around the loads: a re-read is harmless), then tighten the bound -- the other leaves of the node are tested
-        // against it when their turn comes (nearest first)
-        const uint32_t s0 = s_rs[wave][sl], n0 = s_rn[wave][sl];
-        for (uint32_t base = 0; base < n0; base += 64 * kFbLoads) {
-          float4 p[kFbLoads];
+        // it, 128 points per trip with the loads issued back to back (clamped indices, no branches around the loads: a
+        // re-read is harmless), then tighten the bound -- the other leaves of the node are tested against it
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)rs, sl), n0 = (uint32_t)__builtin_amdgcn_readlane((int)rn, sl);
+        for (uint32_t base = 0; base < n0; base += 128) {
+          float4 p[2];
 #pragma unroll
-          for (int k = 0; k < kFbLoads; ++k) {
+          for (int k = 0; k < 2; ++k) {
             const uint32_t gi = base + k * 64 + lane;
             p[k] = sorted[s0 + (gi < n0 ? gi : n0 - 1)];
           }
 #pragma unroll
-          for (int k = 0; k < kFbLoads; ++k) {
+          for (int k = 0; k < 2; ++k) {
             const float d = l2_simple3(qx, qy, qz, p[k].x, p[k].y, p[k].z);
-            const uint64_t key = make_key(d, __float_as_uint(p[k].w));
-            lane_best = key < lane_best ? key : lane_best;
+            lane_best = min_key_f64(lane_best, __builtin_bit_cast(double, make_key(d, __float_as_uint(p[k].w))));
           }
         }
         st_pts += n0;
         ++q_leaves;
-        best = wave_min_u64(lane_best);
+        best = wave_min_u64(__builtin_bit_cast(uint64_t, lane_best));
         best_d = __uint_as_float((uint32_t)(best >> 32));
-        // The node's OTHER leaves that still pass the tightened bound: all of them in one batch -- two leaves' loads in
+        // The node's OTHER leaves that still pass the tightened bound: all of them in one batch -- four leaves' loads in
         // flight at a time, no reduction in between.  They would each be scanned anyway (a leaf on a tilted surface has a
         // fat box: a far query at distance d finds ~d / 0.1 m leaves whose box is nearer than d although none of their
         // points is -- 129 leaf scans in the longest walk of workload M, one walk step each before); the rare leaf that
         // a batch neighbour would have ruled out costs one load.
-        unsigned long long mb = m & __ballot(lb <= best_d);
+        unsigned long long mb = m & __ballot(cur_lb <= best_d);
         if (mb) {
-          m &= ~mb;
-          if (lane == 0) s_mask[wave][lev] = m;
+          cur_m = m & ~mb;
           while (mb) {
-            const int r0 = __ffsll((long long)mb) - 1;
-            mb &= mb - 1;
-            const int r1 = mb ? __ffsll((long long)mb) - 1 : r0;
-            mb &= mb - 1;   // (0 stays 0)
-            const uint32_t a0 = s_rs[wave][r0], c0 = s_rn[wave][r0], a1 = s_rs[wave][r1], c1 = r1 != r0 ? s_rn[wave][r1] : 0u;
-            const uint32_t cmax = c0 > c1 ? c0 : c1;
-            for (uint32_t base = 0; base < cmax; base += 128) {
+            // four leaves per trip, one 64-point load each (a leaf holds ~50 points; the rare longer one loops)
+            uint32_t a[4], c[4];
+            uint32_t cmax = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int r = mb ? __ffsll((long long)mb) - 1 : -1;
+              mb &= mb - 1;   // (0 stays 0)
+              a[k] = r >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)rs, r) : a[0];
+              c[k] = r >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)rn, r) : 0u;
+              cmax = c[k] > cmax ? c[k] : cmax;
+              st_pts += c[k];
+              q_leaves += r >= 0 ? 1 : 0;
+            }
+            for (uint32_t base = 0; base < cmax; base += 64) {
               float4 p[4];
-              const uint32_t g0 = base + lane, g1 = base + 64 + lane;
-              p[0] = sorted[a0 + (g0 < c0 ? g0 : c0 - 1)];
-              p[1] = sorted[a0 + (g1 < c0 ? g1 : c0 - 1)];
-              p[2] = sorted[a1 + (c1 ? (g0 < c1 ? g0 : c1 - 1) : 0u)];
-              p[3] = sorted[a1 + (c1 ? (g1 < c1 ? g1 : c1 - 1) : 0u)];
+              const uint32_t gi = base + lane;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) p[k] = sorted[a[k] + (gi < c[k] ? gi : (c[k] ? c[k] - 1 : 0u))];
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
                 const float d = l2_simple3(qx, qy, qz, p[k].x, p[k].y, p[k].z);
-                const uint64_t key = make_key(d, __float_as_uint(p[k].w));
-                lane_best = key < lane_best ? key : lane_best;
+                lane_best = min_key_f64(lane_best, __builtin_bit_cast(double, make_key(d, __float_as_uint(p[k].w))));
               }
             }
-            st_pts += c0 + c1;
-            q_leaves += r1 != r0 ? 2 : 1;
           }
-          best = wave_min_u64(lane_best);
+          best = wave_min_u64(__builtin_bit_cast(uint64_t, lane_best));
           best_d = __uint_as_float((uint32_t)(best >> 32));
         }
       } else {
+        // push the level, descend into child `sl`
+        s_lb[wave][lev][lane] = cur_lb;
+        if (lane == 0) { s_mask[wave][lev] = cur_m; s_node[wave][lev][0] = nx; s_node[wave][lev][1] = ny; s_node[wave][lev][2] = nz; }
+        if (lev == top) {
+          nx = __builtin_amdgcn_readlane(tcx, sl); ny = __builtin_amdgcn_readlane(tcy, sl); nz = __builtin_amdgcn_readlane(tcz, sl);
+        } else {
+          nx = 4 * nx + (sl & 3); ny = 4 * ny + ((sl >> 2) & 3); nz = 4 * nz + (sl >> 4);
+        }
         --lev;
-        expand = true;
+        PCD_FB_EXPAND();
       }
     }
+#undef PCD_FB_EXPAND
     if (lane == 0) keys[qi] = FUSED ? finalized_key(best) : best;
     st_q += 1;
     st_steps += q_steps; st_leaves += q_leaves;
