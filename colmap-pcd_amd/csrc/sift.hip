@@ -37,13 +37,9 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int kSiftTile = 128;
 constexpr int kSiftPitch = 144;   // bytes per staged descriptor row (128 + 16 pad)
 constexpr int kSiftConst = 128 * 128 * 128;
-#ifndef PCD_SIFT_BBUFS
-#define PCD_SIFT_BBUFS 2
-#endif
 #ifndef PCD_SIFT_WGS
 #define PCD_SIFT_WGS 2
 #endif
-constexpr int kSiftBBufs = PCD_SIFT_BBUFS;   // LDS copies of the set-2 tile in the stripe kernel
 
 __global__ void k_sift_rowsum(const uint8_t* __restrict__ da, int na, int* __restrict__ suma,
                               const uint8_t* __restrict__ db, int nb, int* __restrict__ sumb) {
@@ -199,29 +195,39 @@ __global__ __launch_bounds__(256) void k_sift_scores(const uint8_t* __restrict__
   }
 }
 
-// ---- persistent row-stripe variant -------------------------------------------------------------------
-// Workgroup (by, chunk) keeps the 128-row tile `by` of set 1 in LDS
-// and walks `ct` column tiles of set 2, whose next tile is fetched into registers while the current one is
-// multiplied and scanned (one __syncthreads per tile).  The best-of-set-2 results of the stripe's rows stay
-// in registers across the walk (one partial per chunk); the best-of-set-1 results of a column tile are
-// written per 64-row half (no cross-wave merge inside the loop).  part12 [nchunk][n1], part21 [2 nby][n2].
+// ---- persistent row-stripe variant (round 3: ONE orientation) ----------------------------------------------------
+// Workgroup (by, chunk) owns the 128-row tile `by` of set 1 and walks `ct` column tiles of set 2 (staged through LDS,
+// the next tile fetched into registers while the current one is used; one __syncthreads per tile).  A wavefront owns
+// 64 rows (wr) x the 64-column half wc of every tile and works in blocks of 64 x 32: 8 MFMAs into one of TWO
+// accumulator sets while the other set -- the previous block -- is scanned, so the matrix pipe and the VALU run side
+// by side inside one wavefront (rounds 1-2 computed every tile in both orientations to keep both scans register-local
+// and the two phases of the workgroup's wavefronts ran in step: MFMA time + scan time, 0.13 of the dense i8 peak).
+//   * the set-1 fragments of the wavefront's 64 rows stay in registers for the whole walk (32 VGPRs);
+//   * accumulators are preloaded with the ROW constant 128 rowsum1 (LDS, in C-layout order: no VALU);
+//   * column direction (best set-1 row per set-2 column): register-local in the C layout (lane = column); packed
+//     value = (acc << 8) + code, code = 64 - row (an inline constant per register), 3 VALU per score; one partial
+//     per (64-row half, column) and block, as before;
+//   * row direction (best set-2 column per set-1 row): every lane keeps a running (best, second) for each of its 32
+//     (row, lane-column-class) slots over the WHOLE walk; packed value = (acc << 8) + K, K = (column constant << 8) +
+//     (255 - block sequence number) is one VGPR per block, so the column constant costs nothing: 3 VALU per score.
+//     The 32 lanes that share a row are merged ONCE at the end of the walk, through LDS.
+// part12 [nchunk][n1], part21 [2 nby][n2], as before.  A chunk is at most 128 tiles (8-bit sequence code).
 __device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int n1, const uint8_t* __restrict__ d2,
                                             int n2, const int* __restrict__ sum1, const int* __restrict__ sum2,
                                             int4* __restrict__ part12, int4* __restrict__ part21, int nbx,
                                             int ct_per_chunk, const int chunk, const int by) {
-  __shared__ __attribute__((aligned(16))) uint8_t sA[kSiftTile * kSiftPitch];
-  __shared__ __attribute__((aligned(16))) uint8_t sB[kSiftBBufs][kSiftTile * kSiftPitch];
-  __shared__ int sSumA[kSiftTile], sSumB[kSiftBBufs][kSiftTile];
-  __shared__ int4 sMerge[2][64];   // [64-column half of the stripe][column]
+  __shared__ __attribute__((aligned(16))) uint8_t sB[2][kSiftTile * kSiftPitch];
+  __shared__ int sSumB[2][kSiftTile];
+  __shared__ __attribute__((aligned(16))) int sRc[2][2][32];   // [wr][lane half][mt * 16 + reg]: 128 rowsum1 in C-layout order
+  __shared__ int4 sMerge[2][64];
   const int row0 = by * kSiftTile;
   const int bx0 = chunk * ct_per_chunk, bx1 = min(bx0 + ct_per_chunk, nbx);
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform for the compiler: tile coordinates and LDS bases on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
   if (bx0 >= bx1) return;
 
-  // ---- stage the A tile and the first B tile (re-centred to int8) ----
   uint4 pre[4];
   int presum = 0;
   auto fetch_b = [&](int bx) {
@@ -245,117 +251,141 @@ __device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int 
     if (tid < kSiftTile) sSumB[buf][tid] = presum;
   };
   fetch_b(bx0);
+  // the wavefront's set-1 fragments, straight from global memory (rows past n1: zero descriptors, score 0)
+  v4i fa[2][4];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int c = tid + it * 256, r = c >> 3, q = c & 7;
-    uint4 va = make_uint4(0, 0, 0, 0);
-    if (row0 + r < n1) va = *reinterpret_cast<const uint4*>(d1 + (size_t)(row0 + r) * 128 + q * 16);
-    va.x ^= 0x80808080u; va.y ^= 0x80808080u; va.z ^= 0x80808080u; va.w ^= 0x80808080u;
-    *reinterpret_cast<uint4*>(sA + r * kSiftPitch + q * 16) = va;
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int r = row0 + wr * 64 + mt * 32 + lr;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r < n1) v = *reinterpret_cast<const uint4*>(d1 + (size_t)r * 128 + kk * 32 + lh * 16);
+      fa[mt][kk] = v4i{(int)(v.x ^ 0x80808080u), (int)(v.y ^ 0x80808080u), (int)(v.z ^ 0x80808080u), (int)(v.w ^ 0x80808080u)};
+    }
+  if (tid < kSiftTile) {
+    // row t of the tile sits in register k = (r & 3) + 4 (r >> 3) of lane half (r >> 2) & 1, r = t & 31
+    const int r = tid & 31;
+    sRc[tid >> 6][(r >> 2) & 1][((tid >> 5) & 1) * 16 + (r & 3) + 4 * (r >> 3)] = row0 + tid < n1 ? 128 * sum1[row0 + tid] : 0;
   }
-  if (tid < kSiftTile) sSumA[tid] = row0 + tid < n1 ? sum1[row0 + tid] : 0;
   store_b(0);
   __syncthreads();
+  if (bx0 + 1 < bx1) fetch_b(bx0 + 1);
 
-  // running best-of-set-2 for this wave's two 32-column groups of stripe rows (true scores, global index)
-  int rb[2] = {0, 0}, rs[2] = {0, 0}, ra[2] = {-1, -1};
+  // running row-direction state: packed (true score << 8 | 255 - sequence number); 0 = score 0, no column
+  int rbest[2][16], rsec[2][16];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { rbest[mt][k] = 0; rsec[mt][k] = 0; }
 
+  const v4i* rcp = reinterpret_cast<const v4i*>(&sRc[wr][lh][0]);
+  auto mfma_block = [&](v16i (&acc)[2], int buf, int blk) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4i t = rcp[mt * 4 + q];
+        acc[mt][4 * q] = t[0]; acc[mt][4 * q + 1] = t[1]; acc[mt][4 * q + 2] = t[2]; acc[mt][4 * q + 3] = t[3];
+      }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const v4i fb = *reinterpret_cast<const v4i*>(sB[buf] + (wc * 64 + blk * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mt][kk], fb, acc[mt], 0, 0, 0);
+    }
+  };
+  // cc = the block's column constant 128 rowsum2 - 128^3 of the lane's column (read while the tile's buffer is live)
+  auto scan_block = [&](const v16i (&acc)[2], int cc, int bx, int blk, int seq) {
+    const int init = (int)((unsigned)(-cc) << 8);   // true score 0, code 0 = "no row" (sift.cc:66-68)
+    int cbest = init, csec = init;
+    const int K = (int)((unsigned)cc << 8) + (255 - seq);
+    int tv, tw;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        // 6 VALU per accumulator: v_lshl_add_u32 (pack), v_med3_i32, v_max_i32 for each direction.  Inline asm: hipcc
+        // splits the packs into a shared shift + or + add + add3 (8 per accumulator), and on gfx950 every one of these
+        // integer ops issues at half rate (tools/ubench/valu_rate3.hip: 4.4 cycles per wave64 instruction) -- the scan,
+        // not the MFMAs (36 cycles per 32x32x32), bounds the kernel.
+        // column direction: rows of one lane differ in mt / reg only, so the code is an inline constant
+        asm("v_lshl_add_u32 %2, %3, 8, %4\n\tv_med3_i32 %1, %0, %1, %2\n\tv_max_i32 %0, %0, %2"
+            : "+v"(cbest), "+v"(csec), "=&v"(tv)
+            : "v"(acc[mt][reg]), "n"(64 - (mt * 32 + (reg & 3) + 8 * (reg >> 2))));
+        // row direction
+        asm("v_lshl_add_u32 %2, %3, 8, %4\n\tv_med3_i32 %1, %0, %1, %2\n\tv_max_i32 %0, %0, %2"
+            : "+v"(rbest[mt][reg]), "+v"(rsec[mt][reg]), "=&v"(tw)
+            : "v"(acc[mt][reg]), "v"(K));
+      }
+    // the two lane halves hold interleaved rows (row = ... + 4 lh) of the same column: code -> 68 - row in the
+    // wavefront's 64 rows (the "no row" code stays below every real one)
+    cbest += 4 * (1 - lh); csec += 4 * (1 - lh);
+    {
+      const int b2 = __shfl_xor(cbest, 32), s2 = __shfl_xor(csec, 32);
+      csec = max(max(csec, s2), min(cbest, b2));
+      cbest = max(cbest, b2);
+    }
+    const int bs = (cbest >> 8) + cc, ss = (csec >> 8) + cc;        // true scores (>= 0)
+    const int arg = bs > 0 ? row0 + wr * 64 + 68 - (cbest & 255) : -1;
+    const int gcol = bx * kSiftTile + wc * 64 + blk * 32 + lr;
+    if (lh == 0 && gcol < n2) part21[(size_t)(by * 2 + wr) * n2 + gcol] = make_int4(bs, ss, arg, 0);
+  };
+
+  v16i acc0[2], acc1[2];
+  mfma_block(acc0, 0, 0);
   for (int bx = bx0; bx < bx1; ++bx) {
-    const int buf = kSiftBBufs == 2 ? ((bx - bx0) & 1) : 0;
-    const int col0 = bx * kSiftTile;
-    if (bx + 1 < bx1) fetch_b(bx + 1);   // lands while this tile is multiplied and scanned
-
-    // One orientation at a time over the same 64 accumulator registers: first A.B^T (rows = set 1: the scan gives the
-    // best set-1 row for every set-2 column), then B.A^T.  Computing both at once needed 128 accumulators and held
-    // the kernel at 2 wavefronts per SIMD.
-#pragma unroll
-    for (int dir = 0; dir < 2; ++dir) {
-      v16i acc[2][2];   // dir 0: acc[mt][nt], rows = set 1;  dir 1: acc[nt][mt], rows = set 2
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int rr = a * 32 + (k & 3) + 8 * (k >> 2) + 4 * lh;
-          const int v0 = 128 * (dir == 0 ? sSumA[wr * 64 + rr] : sSumB[buf][wc * 64 + rr]);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) acc[a][c][k] = v0;
-        }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        v4i fa[2], fb[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          fa[t] = *reinterpret_cast<const v4i*>(sA + (wr * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
-          fb[t] = *reinterpret_cast<const v4i*>(sB[buf] + (wc * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            if (dir == 0) acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
-            else acc[nt][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[nt], fa[mt], acc[nt][mt], 0, 0, 0);
-          }
-      }
-      // packed top-2 scan (see k_sift_scores): value = score << 8 | (255 - row in the 128-row tile)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int ccol = (dir == 0 ? wc : wr) * 64 + ct * 32 + lr;
-        const int cconst = 128 * (dir == 0 ? sSumB[buf][ccol] : sSumA[ccol]) - kSiftConst;
-        const int other = dir == 0 ? wr : wc;
-        const int init = (int)((unsigned)(-cconst) << 8);
-        const unsigned code_base = 255u - (unsigned)(other * 64 + 4 * lh);
-        int best = init, second = init;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const v16i& av = acc[rt][ct];
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const unsigned code = code_base - (unsigned)(rt * 32 + (reg & 3) + 8 * (reg >> 2));
-            const int v = (int)(((unsigned)av[reg] << 8) | code);
-            int med;
-            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(med) : "v"(best), "v"(second), "v"(v));
-            second = med;
-            best = max(best, v);
-          }
-        }
-        {
-          const int b2 = __shfl_xor(best, 32), s2 = __shfl_xor(second, 32);
-          second = max(max(second, s2), min(best, b2));
-          best = max(best, b2);
-        }
-        const int bs = (best >> 8) + cconst, ss = (second >> 8) + cconst;        // true scores (>= 0)
-        const int arg = bs > 0 ? (dir == 0 ? row0 : col0) + 255 - (best & 255) : -1;
-        if (dir == 0) {
-          // best set-1 row (of this 64-row half of the stripe) for the tile's set-2 descriptors
-          const int gcol = col0 + ccol;
-          if (lh == 0 && gcol < n2) part21[(size_t)(by * 2 + wr) * n2 + gcol] = make_int4(bs, ss, arg, 0);
-        } else {
-          top2_merge(bs, ss, arg, rb[ct], rs[ct], ra[ct]);   // ascending tiles: ties keep the earlier index
-        }
-      }
-    }
-    if (kSiftBBufs == 2) {
-      if (bx + 1 < bx1) store_b(buf ^ 1);
-      __syncthreads();
-    } else {
-      __syncthreads();                       // every wavefront is done with the tile
-      if (bx + 1 < bx1) store_b(0);
-      __syncthreads();
-    }
+    const int buf = (bx - bx0) & 1;
+    const int cc0 = 128 * sSumB[buf][wc * 64 + lr] - kSiftConst, cc1 = 128 * sSumB[buf][wc * 64 + 32 + lr] - kSiftConst;
+    mfma_block(acc1, buf, 1);
+    scan_block(acc0, cc0, bx, 0, 2 * (bx - bx0));
+    if (bx + 1 < bx1) store_b(buf ^ 1);
+    __syncthreads();
+    if (bx + 2 < bx1) fetch_b(bx + 2);
+    mfma_block(acc0, buf ^ 1, 0);   // (after the last tile: the previous tile once more, unused -- keeps the MFMAs and the scan in one block)
+    scan_block(acc1, cc1, bx, 1, 2 * (bx - bx0) + 1);
   }
 
-  // the two waves that share stripe rows (wc = 0, 1: the two 64-row halves of every column tile) merge
+  // ---- end of the walk: merge the 32 lanes that share a row (through the tile buffers), then the two wavefronts that
+  // share the stripe's rows
+  __syncthreads();   // every wavefront is done with sB
+  int2* tbuf = reinterpret_cast<int2*>(&sB[0][0]) + wave * (32 * 33);   // 32 rows x 33 (pitch) per wavefront: 8448 B of 9216
+  int rb[2], rs[2], ra[2];
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-    if (wc == 1 && lh == 0) sMerge[wr][ct * 32 + lr] = make_int4(rb[ct], rs[ct], ra[ct], 0);
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+      tbuf[((reg & 3) + 8 * (reg >> 2) + 4 * lh) * 33 + lr] = make_int2(rbest[mt][reg], rsec[mt][reg]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the region is this wavefront's own: program order is enough
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // lane (rho = lr, h = lh) merges columns 16 h .. 16 h + 15 of row rho in ascending order
+    int best = 0, second = 0, arg = -1;
+#pragma unroll 4
+    for (int c = 16 * lh; c < 16 * lh + 16; ++c) {
+      const int2 e = tbuf[lr * 33 + c];
+      const int sc = e.x >> 8, seq = 255 - (e.x & 255);
+      const int col = (bx0 + (seq >> 1)) * kSiftTile + wc * 64 + (seq & 1) * 32 + c;
+      top2_merge(sc, e.y >> 8, sc > 0 ? col : -1, best, second, arg);
+    }
+    {
+      const int b2 = __shfl_xor(best, 32), s2 = __shfl_xor(second, 32), a2 = __shfl_xor(arg, 32);
+      top2_merge(b2, s2, a2, best, second, arg);
+    }
+    rb[mt] = best; rs[mt] = second; ra[mt] = arg;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+    if (wc == 1 && lh == 0) sMerge[wr][mt * 32 + lr] = make_int4(rb[mt], rs[mt], ra[mt], 0);
   __syncthreads();
   if (wc == 0 && lh == 0) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int4 o = sMerge[wr][ct * 32 + lr];
-      top2_merge(o.x, o.y, o.z, rb[ct], rs[ct], ra[ct]);
-      const int grow = row0 + wr * 64 + ct * 32 + lr;
-      if (grow < n1) part12[(size_t)chunk * n1 + grow] = make_int4(rb[ct], rs[ct], ra[ct], 0);
+    for (int mt = 0; mt < 2; ++mt) {
+      const int4 o = sMerge[wr][mt * 32 + lr];
+      top2_merge(o.x, o.y, o.z, rb[mt], rs[mt], ra[mt]);
+      const int grow = row0 + wr * 64 + mt * 32 + lr;
+      if (grow < n1) part12[(size_t)chunk * n1 + grow] = make_int4(rb[mt], rs[mt], ra[mt], 0);
     }
   }
 }
@@ -596,7 +626,11 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
   static const int tile_env = std::getenv("PCD_SIFT_TILE") ? std::atoi(std::getenv("PCD_SIFT_TILE")) : 0;
   g_sift_tile_kernel = tile_env;
   // stripe walk: enough (row tile, chunk) workgroups to fill the chip twice over
-  const int nchunk = std::max(1, std::min(nbx, (512 + nby - 1) / nby));
+  // (a chunk is at most 128 column tiles: the stripe kernel's 8-bit sequence code)
+  // PCD_SIFT_NCHUNK (tests / fuzzing): force the number of column chunks, e.g. 1 = every stripe walks all tiles
+  static const int nchunk_env = std::getenv("PCD_SIFT_NCHUNK") ? std::atoi(std::getenv("PCD_SIFT_NCHUNK")) : 0;
+  const int want = nchunk_env > 0 ? std::min(nchunk_env, nbx) : std::min(nbx, (512 + nby - 1) / nby);
+  const int nchunk = std::max({1, want, (nbx + 127) / 128});
   const int ct_per_chunk = (nbx + nchunk - 1) / nchunk;
   const int nchunk_used = (nbx + ct_per_chunk - 1) / ct_per_chunk;
   PCD_TRY(sc.sum1.reserve(n1)); PCD_TRY(sc.sum2.reserve(n2));
@@ -656,6 +690,7 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
   const char* budget_env = std::getenv("PCD_SIFT_BATCH_PARTIALS");
   const size_t budget = budget_env ? (size_t)std::strtoull(budget_env, nullptr, 10) : kSiftBatchPartials;
   for (int i = 0; i < n_images; ++i) PCD_REQUIRE(first_row[i] <= first_row[i + 1], "first_row must ascend");
+  uint64_t max_nbx = 1;
   bool wide = false;   // a set too long for the one-workgroup compaction: those batches run pair by pair
   for (int p = 0; p < n_pairs; ++p) {
     PCD_REQUIRE(pair_ids[2 * p] < (uint32_t)n_images && pair_ids[2 * p + 1] < (uint32_t)n_images, "pair names an image outside the arena");
@@ -663,6 +698,7 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
     const uint64_t n2 = first_row[pair_ids[2 * p + 1] + 1] - first_row[pair_ids[2 * p + 1]];
     PCD_REQUIRE(n1 < (1u << 30) && n2 < (1u << 30), "image too large");
     wide = wide || n1 > (uint64_t)1024 * kCompactPer;
+    max_nbx = std::max(max_nbx, (n2 + kSiftTile - 1) / kSiftTile);
   }
   if (wide) {
     for (int p = 0; p < n_pairs; ++p) {
@@ -697,7 +733,9 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
       const int nby0 = std::max<int>(1, (int)((first_row[a0 + 1] - first_row[a0] + kSiftTile - 1) / kSiftTile));
       const int nbx0 = std::max<int>(1, (int)((first_row[b0 + 1] - first_row[b0] + kSiftTile - 1) / kSiftTile));
       const long left = n_pairs - p0;
-      const int nchunk = (int)std::max<long>(1, std::min<long>(nbx0, (512 + nby0 * left - 1) / (nby0 * left)));
+      static const int nchunk_env = std::getenv("PCD_SIFT_NCHUNK") ? std::atoi(std::getenv("PCD_SIFT_NCHUNK")) : 0;
+      const long want = nchunk_env > 0 ? std::min<long>(nchunk_env, nbx0) : std::min<long>(nbx0, (512 + nby0 * left - 1) / (nby0 * left));
+      const int nchunk = (int)std::max<long>({1, want, (long)((max_nbx + 127) / 128)});   // a chunk is at most 128 column tiles
       size_t o12 = 0, o21 = 0, om12 = 0, om21 = 0;
       int p = p0;
       for (; p < n_pairs; ++p) {

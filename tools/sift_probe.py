@@ -46,7 +46,8 @@ print("k_sift_scores: %.3f ms, %.1f TOP/s int8 MFMA executed (useful %.1f), dens
 
 # ---- a block of the exhaustive matcher through the batched entry (SiftFeatureMatcher::Match(image_pairs),
 # feature/matching.cc:798; ExhaustiveMatchingOptions::block_size = 50 images) ----
-for n_img, n_desc in ((16, n1), (50, n1), (50, 2048)):
+ONLY = os.environ.get("PROBE_ONLY_BLOCK", "0") == "1"   # profiling: just the 50-image block
+for n_img, n_desc in ((50, n1),) if ONLY else ((16, n1), (50, n1), (50, 2048)):
     first = np.arange(n_img + 1, dtype=np.uint64) * np.uint64(n_desc)
     base = np.clip(np.round(512 * f[:n_desc]), 0, 255).astype(np.int32)
     arena = np.concatenate([np.clip(base[rng.permutation(n_desc)] + rng.integers(-5, 6, (n_desc, 128)), 0, 255).astype(np.uint8)

@@ -1,0 +1,104 @@
+// valu_rate3.hip -- integer VALU rates of the SIFT top-2 scan and their overlap with i8 MFMAs on gfx950.
+// hipcc --offload-arch=gfx950 -O3 valu_rate3.hip -o valu_rate3
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+#define REP8(x) x x x x x x x x
+#define A8 "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+#define I8(op) op " %0, %0, %1\n" op " %1, %1, %2\n" op " %2, %2, %3\n" op " %3, %3, %4\n" op " %4, %4, %5\n" op " %5, %5, %6\n" op " %6, %6, %7\n" op " %7, %7, %0"
+#define T8(op) op " %0, %0, %1, %2\n" op " %1, %1, %2, %3\n" op " %2, %2, %3, %4\n" op " %3, %3, %4, %5\n" op " %4, %4, %5, %6\n" op " %5, %5, %6, %7\n" op " %6, %6, %7, %0\n" op " %7, %7, %0, %1"
+#define L8(op) op " %0, %0, 8, %1\n" op " %1, %1, 8, %2\n" op " %2, %2, 8, %3\n" op " %3, %3, 8, %4\n" op " %4, %4, 8, %5\n" op " %5, %5, 8, %6\n" op " %6, %6, 8, %7\n" op " %7, %7, 8, %0"
+#define C8(op) op " %0, %0, 8, 17\n" op " %1, %1, 8, 18\n" op " %2, %2, 8, 19\n" op " %3, %3, 8, 20\n" op " %4, %4, 8, 21\n" op " %5, %5, 8, 22\n" op " %6, %6, 8, 23\n" op " %7, %7, 8, 24"
+// the scan of one accumulator value in both directions: 6 instructions
+#define SCAN(acc) "v_lshl_add_u32 %4, " acc ", 8, 33\n v_med3_i32 %1, %0, %1, %4\n v_max_i32 %0, %0, %4\n" \
+                  "v_lshl_add_u32 %5, " acc ", 8, %6\n v_med3_i32 %3, %2, %3, %5\n v_max_i32 %2, %2, %5\n"
+
+template <int OP>
+__global__ __launch_bounds__(256, 2) void k(int* out, int iters, int s0) {
+  int a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  v16i c0 = {0}, c1 = {0};
+  v4i fa = {a0, a1, a2, a3}, fb = {a4, a5, a6, a7};
+  int t0 = 0, t1 = 0;
+  for (int i = 0; i < iters; ++i) {
+    if (OP == 0) { REP8(asm volatile(I8("v_max_i32") : A8);) }
+    if (OP == 1) { REP8(asm volatile(T8("v_med3_i32") : A8);) }
+    if (OP == 2) { REP8(asm volatile(L8("v_lshl_add_u32") : A8);) }
+    if (OP == 3) { REP8(asm volatile(C8("v_lshl_add_u32") : A8);) }
+    if (OP == 4) { REP8(asm volatile(T8("v_max3_i32") : A8);) }
+    if (OP == 5) { REP8(asm volatile(I8("v_add_u32") : A8);) }
+    if (OP == 6) { REP8(asm volatile(L8("v_lshl_or_b32") : A8);) }
+    if (OP == 7) {   // 32 accumulator values scanned in both directions: 192 VALU
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        asm volatile(SCAN("%7") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1) : "v"(a4), "v"(c0[r]));
+        asm volatile(SCAN("%7") : "+v"(a0), "+v"(a1), "+v"(a5), "+v"(a6), "=&v"(t0), "=&v"(t1) : "v"(a4), "v"(c1[r]));
+      }
+    }
+    if (OP == 8) {   // 8 MFMAs alone
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb, fa, c1, 0, 0, 0);
+      }
+    }
+    if (OP == 9 || OP == 10) {   // 8 MFMAs into one accumulator pair while the other pair is scanned (192 VALU); roles swap
+      v16i d0 = {0}, d1 = {0};
+#define PHASE(X0, X1, Y0, Y1)                                                                                          \
+      _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                                  \
+        X0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, X0, 0, 0, 0);                                               \
+        if (OP == 10) X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb, fa, X1, 0, 0, 0);                                 \
+        _Pragma("unroll") for (int r = 4 * m; r < 4 * m + 2; ++r) {                                                   \
+          asm volatile(SCAN("%7") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1) : "v"(a4), "v"(Y0[r])); \
+          asm volatile(SCAN("%7") : "+v"(a0), "+v"(a1), "+v"(a5), "+v"(a6), "=&v"(t0), "=&v"(t1) : "v"(a4), "v"(Y1[r])); \
+        }                                                                                                              \
+        if (OP == 9) X1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb, fa, X1, 0, 0, 0);                                  \
+        _Pragma("unroll") for (int r = 4 * m + 2; r < 4 * m + 4; ++r) {                                               \
+          asm volatile(SCAN("%7") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1) : "v"(a4), "v"(Y0[r])); \
+          asm volatile(SCAN("%7") : "+v"(a0), "+v"(a1), "+v"(a5), "+v"(a6), "=&v"(t0), "=&v"(t1) : "v"(a4), "v"(Y1[r])); \
+        }                                                                                                              \
+      }
+      PHASE(d0, d1, c0, c1)
+      PHASE(c0, c1, d0, d1)
+      a7 += d0[3] + d1[5];
+    }
+  }
+  int acc = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + t0 + t1;
+  for (int r = 0; r < 16; ++r) acc += c0[r] + c1[r];
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int OP>
+void run(const char* name, int instr_per_iter, int w) {
+  const int blocks = 256 * w;
+  int* out; (void)hipMalloc(&out, blocks * 256 * sizeof(int));
+  const int iters = 2000;
+  hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  k<OP><<<blocks, 256>>>(out, 100, 1);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(a);
+  k<OP><<<blocks, 256>>>(out, iters, 1);
+  (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+  float ms; (void)hipEventElapsedTime(&ms, a, b);
+  const double winst = (double)w * iters * instr_per_iter;
+  printf("%-52s waves/SIMD %d: %.3f ms -> %.2f ns per wave-instr per SIMD (%.1f ns per iteration per wave)\n", name, w, ms,
+         ms * 1e6 / winst, ms * 1e6 / ((double)w * iters));
+  (void)hipFree(out);
+}
+
+int main() {
+  for (int w : {1, 2}) {
+    run<0>("v_max_i32", 64, w);
+    run<1>("v_med3_i32", 64, w);
+    run<2>("v_lshl_add_u32 v,8,v", 64, w);
+    run<3>("v_lshl_add_u32 v,8,inline", 64, w);
+    run<4>("v_max3_i32", 64, w);
+    run<5>("v_add_u32", 64, w);
+    run<6>("v_lshl_or_b32", 64, w);
+    run<7>("scan of 32 accumulators, both directions (192)", 192, w);
+    run<8>("8 x v_mfma_i32_32x32x32_i8", 8, w);
+    run<9>("2 x (8 MFMA spread through the 192-VALU scan)", 400, w);
+    run<10>("2 x (MFMAs in pairs, then 48 VALU)", 400, w);
+  }
+  return 0;
+}
