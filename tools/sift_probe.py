@@ -39,10 +39,9 @@ pcdhip.profile_enable(False)
 for k, (n, t) in p.items():
     print("  %-16s %8.3f ms/launch" % (k, t / n))
 sc = p["sift_scores"][1] / p["sift_scores"][0]
-ops = 2.0 * 2 * 128 * n1 * n2          # the tile is computed in both orientations
+ops = 2.0 * 128 * n1 * n2              # one S = D1.D2^T (round 3: every tile is multiplied once)
 print("pair %d x %d: %.3f ms -> %.0f pairs/s; %d matches" % (n1, n2, ms, 1e3 / ms, int(cnt.item())))
-print("k_sift_scores: %.3f ms, %.1f TOP/s int8 MFMA executed (useful %.1f), dense i8 peak ~5000 TOP/s"
-      % (sc, ops / sc / 1e9, ops / 2 / sc / 1e9))
+print("k_sift_scores: %.3f ms, %.1f TOP/s int8 MFMA (executed = useful), dense i8 peak ~5000 TOP/s" % (sc, ops / sc / 1e9))
 
 # ---- a block of the exhaustive matcher through the batched entry (SiftFeatureMatcher::Match(image_pairs),
 # feature/matching.cc:798; ExhaustiveMatchingOptions::block_size = 50 images) ----
@@ -68,7 +67,7 @@ for n_img, n_desc in ((50, n1),) if ONLY else ((16, n1), (50, n1), (50, 2048)):
     ms = e0.elapsed_time(e1)
     useful = 2.0 * 128 * n_desc * n_desc * P
     print("batch: %d images x %d descriptors, %d pairs: %.2f ms = %.3f ms/pair -> %.0f pairs/s, %.1f useful TOP/s "
-          "(one S = D1.D2^T per pair; executed 2x), %d matches"
+          "(one S = D1.D2^T per pair), %d matches"
           % (n_img, n_desc, P, ms, ms / P, P / ms * 1e3, useful / ms / 1e9, int(d_c.sum().item())), flush=True)
     # the same pairs one call each (what the single-pair entry costs)
     if P <= 200:

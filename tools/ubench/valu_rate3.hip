@@ -15,7 +15,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
                   "v_lshl_add_u32 %5, " acc ", 8, %6\n v_med3_i32 %3, %2, %3, %5\n v_max_i32 %2, %2, %5\n"
 
 template <int OP>
-__global__ __launch_bounds__(256, 2) void k(int* out, int iters, int s0) {
+__global__ __launch_bounds__(256, 4) void k(int* out, int iters, int s0) {
   int a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   v16i c0 = {0}, c1 = {0};
   v4i fa = {a0, a1, a2, a3}, fb = {a4, a5, a6, a7};
@@ -28,6 +28,21 @@ __global__ __launch_bounds__(256, 2) void k(int* out, int iters, int s0) {
     if (OP == 4) { REP8(asm volatile(T8("v_max3_i32") : A8);) }
     if (OP == 5) { REP8(asm volatile(I8("v_add_u32") : A8);) }
     if (OP == 6) { REP8(asm volatile(L8("v_lshl_or_b32") : A8);) }
+    if (OP == 11) { REP8(asm volatile(T8("v_mad_i32_i24") : A8);) }
+    if (OP == 12) { REP8(asm volatile(T8("v_mad_u32_u24") : A8);) }
+    if (OP == 13) { REP8(asm volatile(I8("v_lshlrev_b32") : A8);) }
+    if (OP == 14) { REP8(asm volatile(I8("v_mul_u32_u24") : A8);) }
+    if (OP == 15) { REP8(asm volatile(I8("v_max_u32") : A8);) }
+    if (OP == 16) { REP8(asm volatile(I8("v_max_f32") : A8);) }
+    if (OP == 17) { REP8(asm volatile(T8("v_med3_f32") : A8);) }
+    if (OP == 18) { REP8(asm volatile(I8("v_pk_max_i16") : A8);) }
+    if (OP == 19) { REP8(asm volatile(I8("v_max_i16") : A8);) }
+    if (OP == 20) { REP8(asm volatile(T8("v_fma_f32") : A8);) }
+    if (OP == 21) { REP8(asm volatile(T8("v_add3_u32") : A8);) }
+    if (OP == 22) { REP8(asm volatile(T8("v_and_or_b32") : A8);) }
+    if (OP == 23) { REP8(asm volatile(T8("v_perm_b32") : A8);) }
+    if (OP == 24) { REP8(asm volatile(T8("v_alignbit_b32") : A8);) }
+    if (OP == 25) { REP8(asm volatile(I8("v_or_b32") : A8);) }
     if (OP == 7) {   // 32 accumulator values scanned in both directions: 192 VALU
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -87,7 +102,7 @@ void run(const char* name, int instr_per_iter, int w) {
 }
 
 int main() {
-  for (int w : {1, 2}) {
+  for (int w : {2, 4}) {
     run<0>("v_max_i32", 64, w);
     run<1>("v_med3_i32", 64, w);
     run<2>("v_lshl_add_u32 v,8,v", 64, w);
@@ -95,6 +110,21 @@ int main() {
     run<4>("v_max3_i32", 64, w);
     run<5>("v_add_u32", 64, w);
     run<6>("v_lshl_or_b32", 64, w);
+    run<11>("v_mad_i32_i24", 64, w);
+    run<12>("v_mad_u32_u24", 64, w);
+    run<13>("v_lshlrev_b32", 64, w);
+    run<14>("v_mul_u32_u24", 64, w);
+    run<15>("v_max_u32", 64, w);
+    run<16>("v_max_f32", 64, w);
+    run<17>("v_med3_f32", 64, w);
+    run<18>("v_pk_max_i16", 64, w);
+    run<19>("v_max_i16", 64, w);
+    run<20>("v_fma_f32", 64, w);
+    run<21>("v_add3_u32", 64, w);
+    run<22>("v_and_or_b32", 64, w);
+    run<23>("v_perm_b32", 64, w);
+    run<24>("v_alignbit_b32", 64, w);
+    run<25>("v_or_b32", 64, w);
     run<7>("scan of 32 accumulators, both directions (192)", 192, w);
     run<8>("8 x v_mfma_i32_32x32x32_i8", 8, w);
     run<9>("2 x (8 MFMA spread through the 192-VALU scan)", 400, w);
