@@ -628,7 +628,8 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
   // stripe walk: enough (row tile, chunk) workgroups to fill the chip twice over
   // (a chunk is at most 128 column tiles: the stripe kernel's 8-bit sequence code)
   // PCD_SIFT_NCHUNK (tests / fuzzing): force the number of column chunks, e.g. 1 = every stripe walks all tiles
-  static const int nchunk_env = std::getenv("PCD_SIFT_NCHUNK") ? std::atoi(std::getenv("PCD_SIFT_NCHUNK")) : 0;
+  const char* nce = std::getenv("PCD_SIFT_NCHUNK");   // read per call: tests switch it inside one process
+  const int nchunk_env = nce ? std::atoi(nce) : 0;
   const int want = nchunk_env > 0 ? std::min(nchunk_env, nbx) : std::min(nbx, (512 + nby - 1) / nby);
   const int nchunk = std::max({1, want, (nbx + 127) / 128});
   const int ct_per_chunk = (nbx + nchunk - 1) / nchunk;
@@ -733,7 +734,8 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
       const int nby0 = std::max<int>(1, (int)((first_row[a0 + 1] - first_row[a0] + kSiftTile - 1) / kSiftTile));
       const int nbx0 = std::max<int>(1, (int)((first_row[b0 + 1] - first_row[b0] + kSiftTile - 1) / kSiftTile));
       const long left = n_pairs - p0;
-      static const int nchunk_env = std::getenv("PCD_SIFT_NCHUNK") ? std::atoi(std::getenv("PCD_SIFT_NCHUNK")) : 0;
+      const char* nce = std::getenv("PCD_SIFT_NCHUNK");
+      const int nchunk_env = nce ? std::atoi(nce) : 0;
       const long want = nchunk_env > 0 ? std::min<long>(nchunk_env, nbx0) : std::min<long>(nbx0, (512 + nby0 * left - 1) / (nby0 * left));
       const int nchunk = (int)std::max<long>({1, want, (long)((max_nbx + 127) / 128)});   // a chunk is at most 128 column tiles
       size_t o12 = 0, o21 = 0, om12 = 0, om21 = 0;

@@ -43,6 +43,31 @@ def test_random_descriptors_exact(gpu, oracle, n1, n2, cross):
         assert len(exp) > 10               # the test set really produces matches
 
 
+@pytest.mark.parametrize("nchunk", [1, 2, 5])
+def test_long_walks_with_ties(gpu, oracle, nchunk, monkeypatch):
+    """the stripe kernel's running row-direction state over MANY column tiles (PCD_SIFT_NCHUNK forces the number of
+    column chunks; the default picks one tile per chunk at these sizes): few distinct descriptors => equal best
+    scores in different tiles, blocks, lanes and chunks, so every tie rule of the end-of-walk merge decides"""
+    monkeypatch.setenv("PCD_SIFT_NCHUNK", str(nchunk))
+    rng = np.random.default_rng(100 + nchunk)
+    n1, n2 = 700, 1900                                   # 6 row tiles x 15 column tiles
+    base = rng.integers(0, 90, (6, 128), dtype=np.uint8)
+    d1 = base[rng.integers(0, 6, n1)].copy()
+    d2 = base[rng.integers(0, 6, n2)].copy()
+    d2[::3] = np.clip(d2[::3].astype(np.int32) + rng.integers(0, 2, (len(d2[::3]), 128)), 0, 255).astype(np.uint8)
+    d1[5] = 0
+    d2[1234] = 255
+    for cross, ratio, dist in ((True, 0.8, 0.7), (False, 1.0, 3.2), (True, 1.0, 3.2)):
+        exp, e12, e21 = oracle.sift_match(d1, d2, max_ratio=ratio, max_distance=dist, cross_check=cross)
+        got = gpu.sift_match(d1, d2, max_ratio=ratio, max_distance=dist, cross_check=cross)
+        assert np.array_equal(got, exp), (nchunk, cross, ratio, len(got), len(exp))
+    # the batched entry on the same two sets (both orders)
+    pairs = np.array([[0, 1], [1, 0]], np.uint32)
+    res = gpu.sift_match_batch([d1, d2], pairs, max_ratio=1.0, max_distance=3.2, cross_check=True)
+    assert np.array_equal(res[0], oracle.sift_match(d1, d2, max_ratio=1.0, max_distance=3.2, cross_check=True)[0])
+    assert np.array_equal(res[1], oracle.sift_match(d2, d1, max_ratio=1.0, max_distance=3.2, cross_check=True)[0])
+
+
 def test_one_way_results_and_asymmetric_layout_check(gpu, oracle):
     """device API: m12 / m21 equal the oracle's one-way results; the inputs are asymmetric (different sizes,
     different contents per row and per column) so a transposed or permuted MFMA result layout cannot pass"""
