@@ -462,6 +462,33 @@ def main():
                                     useful_TOPs=useful, useful_frac_of_dense_i8_peak=useful / 5000.0,
                                     matches=int(d_c.sum().item()), config5_450_images_s=101025 * t_sift / len(pairs))
         del d_arena, d_m, d_c
+        # config 5 itself: 450 images, all 101 025 pairs, block by block as ExhaustiveFeatureMatcher::Run
+        # (feature/matching.cc:902-960) -- measured, not extrapolated (tests/test_sift_gpu.py checks the same sweep)
+        n_img = 450
+        pool = torch.from_numpy(np.concatenate([base, base[::-1]]).astype(np.int16)).to(dev)
+        gen = torch.Generator(device=dev).manual_seed(7)
+        d_arena = torch.empty((n_img * n_desc, 128), dtype=torch.uint8, device=dev)
+        for i in range(n_img):
+            pick = torch.randperm(2 * n_desc, device=dev, generator=gen)[:n_desc]
+            noise = torch.randint(-5, 6, (n_desc, 128), device=dev, generator=gen, dtype=torch.int16)
+            d_arena[i * n_desc:(i + 1) * n_desc] = (pool[pick] + noise).clamp_(0, 255).to(torch.uint8)
+        first = np.arange(n_img + 1, dtype=np.uint64) * np.uint64(n_desc)
+        d_m = torch.empty(2500 * n_desc, 2, dtype=torch.int32, device=dev)
+        d_c = torch.empty(2500, dtype=torch.int32, device=dev)
+        blocks = [b for b in pcdhip.exhaustive_blocks(n_img, 50) if len(b)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_pairs = 0
+        for pr in blocks:
+            pcdhip.sift_match_batch_device(d_arena, first, pr, d_m, np.arange(len(pr), dtype=np.uint64) * np.uint64(n_desc), d_c,
+                                           device=local_rank, stream=stream)
+            n_pairs += len(pr)
+        torch.cuda.synchronize()
+        t_c5 = time.perf_counter() - t0
+        extras["sift_config5"] = dict(workload=f"{n_img} images x {n_desc} descriptors, exhaustive: {n_pairs} pairs in {len(blocks)} blocks of <= 50 x 50 images",
+                                      seconds=t_c5, pairs_per_sec=n_pairs / t_c5,
+                                      useful_TOPs=2.0 * 128 * n_desc * n_desc * n_pairs / t_c5 / 1e12)
+        del d_arena, d_m, d_c, pool
 
     # ---- the Ceres route end to end (shim/ceres_adapter.h): PrepareForEvaluation with Jacobians + one sweep of every
     # block's Evaluate, PCIe included -- what a colmap user's ceres::Solve sees per evaluation (C++ harness, run as a

@@ -459,6 +459,22 @@ def sift_match_batch(descriptors, pairs, max_ratio=0.8, max_distance=0.7, cross_
     return [m[int(off[p]):int(off[p + 1])].copy() for p in range(P)]
 
 
+def exhaustive_blocks(n_images, block_size=50):
+    """The image-pair lists of ExhaustiveFeatureMatcher::Run (feature/matching.cc:902-960), one per block pair, in the
+    reference's order: blocks of `block_size` consecutive images, pair (i1, i2) taken when
+    (i1 > i2 and i1 % B <= i2 % B) or (i1 < i2 and i1 % B < i2 % B) -- every unordered pair exactly once.  Each list
+    is what the reference hands to SiftFeatureMatcher::Match(image_pairs) = sift_match_batch[_device]."""
+    B = int(block_size)
+    for s1 in range(0, n_images, B):
+        e1 = min(n_images, s1 + B)
+        for s2 in range(0, n_images, B):
+            e2 = min(n_images, s2 + B)
+            i1, i2 = np.meshgrid(np.arange(s1, e1), np.arange(s2, e2), indexing="ij")
+            b1, b2 = i1 % B, i2 % B
+            keep = ((i1 > i2) & (b1 <= b2)) | ((i1 < i2) & (b1 < b2))
+            yield np.stack([i1[keep], i2[keep]], axis=1).astype(np.uint32)
+
+
 def sift_match_batch_device(d_arena, first_row, pairs, d_matches, match_offset, d_counts, max_ratio=0.8,
                             max_distance=0.7, cross_check=True, device=0, stream=0):
     """device form: first_row / pairs / match_offset are numpy (host) arrays, the rest torch device tensors"""

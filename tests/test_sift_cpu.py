@@ -50,3 +50,34 @@ def test_sift_distance_matrix_and_one_way_rules(oracle):
     dd = np.concatenate([d, d[:1]])                                              # d[0] appears twice in set 2
     m, m12, m21 = oracle.sift_match(d, dd, cross_check=False)
     assert m12[0] == -1 and (m12[1:] == np.arange(1, 10)).all()
+
+
+def test_exhaustive_block_enumeration():
+    """pcdhip.exhaustive_blocks against a loop-for-loop restatement of ExhaustiveFeatureMatcher::Run's pair rule
+    (feature/matching.cc:921-953): same blocks, same pairs in the same order, every unordered pair exactly once"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "colmap-pcd_amd"))
+    import pcdhip
+    for n, B in ((1, 50), (2, 50), (23, 5), (50, 50), (51, 50), (120, 50), (7, 3)):
+        blocks = list(pcdhip.exhaustive_blocks(n, B))
+        want = []
+        for s1 in range(0, n, B):
+            e1 = min(n, s1 + B) - 1
+            for s2 in range(0, n, B):
+                e2 = min(n, s2 + B) - 1
+                pr = []
+                for i1 in range(s1, e1 + 1):
+                    for i2 in range(s2, e2 + 1):
+                        b1, b2 = i1 % B, i2 % B
+                        if (i1 > i2 and b1 <= b2) or (i1 < i2 and b1 < b2):
+                            pr.append((i1, i2))
+                want.append(pr)
+        assert len(blocks) == len(want)
+        seen = set()
+        for got, w in zip(blocks, want):
+            assert [tuple(int(v) for v in r) for r in got] == w
+            for a, b in w:
+                key = (min(a, b), max(a, b))
+                assert key not in seen
+                seen.add(key)
+        assert len(seen) == n * (n - 1) // 2

@@ -179,3 +179,65 @@ def test_batch_full_size_block(gpu):
     for (a, b), g in zip(pairs, got):
         assert np.array_equal(g, gpu.sift_match(imgs[a], imgs[b])), (a, b)
     assert sum(len(g) for g in got) > 15 * 2000
+
+
+def test_config5_exhaustive_sweep_450_images(gpu):
+    """BASELINE.json config 5 end to end: 450 images x 8192 descriptors, every pair once (101 025 pairs), block by
+    block as ExhaustiveFeatureMatcher::Run does (feature/matching.cc:902-960, block_size 50), each block one
+    pcd_sift_match_batch_device call.  Checked: the block enumeration covers every unordered pair exactly once; every
+    pair of a sample (in every block) has exactly the match list of the single-pair entry (itself oracle-checked
+    above); all lists are strictly ascending in the first index and inside their capacity."""
+    import time
+    rng = np.random.default_rng(2024)
+    n_img, n_desc = 450, 8192
+    f = rng.random((2 * n_desc, 128), dtype=np.float32) ** 2
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    pool = torch.from_numpy(np.clip(np.round(512 * f), 0, 255).astype(np.int16)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    arena = torch.empty((n_img * n_desc, 128), dtype=torch.uint8, device="cuda")
+    for i in range(n_img):   # every image: a noisy subset of one pool (the images really share features)
+        pick = torch.randperm(2 * n_desc, device="cuda", generator=g)[:n_desc]
+        noise = torch.randint(-5, 6, (n_desc, 128), device="cuda", generator=g, dtype=torch.int16)
+        arena[i * n_desc:(i + 1) * n_desc] = (pool[pick] + noise).clamp_(0, 255).to(torch.uint8)
+    first = np.arange(n_img + 1, dtype=np.uint64) * np.uint64(n_desc)
+    max_pairs = 50 * 50
+    d_m = torch.empty((max_pairs * n_desc, 2), dtype=torch.int32, device="cuda")
+    d_c = torch.empty(max_pairs, dtype=torch.int32, device="cuda")
+    m12 = torch.empty(n_desc, dtype=torch.int32, device="cuda")
+    m21 = torch.empty(n_desc, dtype=torch.int32, device="cuda")
+    mm = torch.empty((n_desc, 2), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    seen = np.zeros((n_img, n_img), bool)
+    total_pairs = total_matches = 0
+    t_batch = 0.0
+    for pairs in gpu.exhaustive_blocks(n_img, 50):
+        P = len(pairs)
+        if P == 0:
+            continue
+        assert P <= max_pairs
+        a, b = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+        assert not seen[a, b].any() and not seen[b, a].any()
+        seen[a, b] = True
+        off = np.arange(P, dtype=np.uint64) * np.uint64(n_desc)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gpu.sift_match_batch_device(arena, first, pairs, d_m, off, d_c)
+        torch.cuda.synchronize()
+        t_batch += time.perf_counter() - t0
+        c = d_c[:P].cpu().numpy()
+        assert (c >= 0).all() and (c <= n_desc).all()
+        total_pairs += P
+        total_matches += int(c.sum())
+        for p in rng.choice(P, 2, replace=False):   # two pairs of every block against the single-pair entry
+            i, j = int(a[p]), int(b[p])
+            gpu.sift_match_device(arena[i * n_desc:(i + 1) * n_desc], n_desc, arena[j * n_desc:(j + 1) * n_desc], n_desc,
+                                  m12, m21, mm, cnt)
+            k = int(cnt.item())
+            assert k == int(c[p]), (i, j, k, int(c[p]))
+            got = d_m[p * n_desc: p * n_desc + k]
+            assert torch.equal(got, mm[:k]), (i, j)
+            assert bool((got[1:, 0] > got[:-1, 0]).all())
+    assert total_pairs == n_img * (n_img - 1) // 2 == 101025
+    assert (seen | seen.T | np.eye(n_img, dtype=bool)).all()
+    assert total_matches > 1000 * total_pairs        # the images share features: thousands of matches per pair
+    print(f"config 5: {total_pairs} pairs in {t_batch:.2f} s of batched calls, {total_matches / total_pairs:.0f} matches per pair")
