@@ -66,7 +66,7 @@ __device__ __forceinline__ void assoc_core(const double X[3], const float p[3], 
   if (o.dist2plane) o.dist2plane[i] = d2p;
 }
 
-__global__ void k_associate(const float4* __restrict__ pts4, const float4* __restrict__ nrm4, ShardIndex si,
+__global__ void k_associate(const float4* __restrict__ pn8, ShardIndex si,
                             const double* __restrict__ q, uint64_t Q,
                             const uint64_t* __restrict__ keys, const double* __restrict__ max_range,
                             uint64_t mr_count, int mode, AssocOut o) {
@@ -81,7 +81,7 @@ __global__ void k_associate(const float4* __restrict__ pts4, const float4* __res
     // must not be mapped onto one of this shard's rows
     const uint64_t li = shard_local_row(si, gi);
     if (li != ~0ull) {
-      const float4 a = pts4[li], b = nrm4[li];
+      const float4 a = pn8[2 * li], b = pn8[2 * li + 1];   // one 32-byte record: point + normal
       p[0] = a.x; p[1] = a.y; p[2] = a.z;
       nv[0] = b.x; nv[1] = b.y; nv[2] = b.z;
     } else {
@@ -96,7 +96,7 @@ __global__ void k_associate(const float4* __restrict__ pts4, const float4* __res
 }
 
 // winner (xyz, normal) of the keys this shard owns, as int32 bit patterns; zeros elsewhere
-__global__ void k_winner_payload(const float4* __restrict__ pts4, const float4* __restrict__ nrm4, ShardIndex si,
+__global__ void k_winner_payload(const float4* __restrict__ pn8, ShardIndex si,
                                  const uint64_t* __restrict__ keys, uint64_t Q, int32_t* __restrict__ payload) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= Q) return;
@@ -105,7 +105,7 @@ __global__ void k_winner_payload(const float4* __restrict__ pts4, const float4* 
   if (key != PCD_KEY_NONE) {
     const uint64_t li = shard_local_row(si, (uint32_t)key);
     if (li != ~0ull) {
-      const float4 a = pts4[li], b = nrm4[li];
+      const float4 a = pn8[2 * li], b = pn8[2 * li + 1];
       out[0] = __float_as_int(a.x); out[1] = __float_as_int(a.y); out[2] = __float_as_int(a.z);
       out[3] = __float_as_int(b.x); out[4] = __float_as_int(b.y); out[5] = __float_as_int(b.z);
     }
@@ -216,7 +216,7 @@ pcd_status pcd_associate_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q,
   }
   {
     ScopedKernelTimer t("associate", s);
-    hipLaunchKernelGGL(k_associate, dim3(div_up(Q, 256)), dim3(256), 0, s, c->pts4.p, c->nrm4.p, c->shard_index(),
+    hipLaunchKernelGGL(k_associate, dim3(div_up(Q, 256)), dim3(256), 0, s, c->pn8.p, c->shard_index(),
                        d_q_xyz, Q, keys, gate_mode == PCD_GATE_CONTROLLER ? nullptr : d_max_range,
                        max_range_count, gate_mode, to_dev(d_out));
   }
@@ -231,7 +231,7 @@ pcd_status pcd_nn_winner_payload_device(pcd_cloud* c, const uint64_t* d_keys, ui
   PCD_HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
   ScopedKernelTimer t("winner_payload", s);
-  hipLaunchKernelGGL(k_winner_payload, dim3(div_up(Q, 256)), dim3(256), 0, s, c->pts4.p, c->nrm4.p, c->shard_index(),
+  hipLaunchKernelGGL(k_winner_payload, dim3(div_up(Q, 256)), dim3(256), 0, s, c->pn8.p, c->shard_index(),
                      d_keys, Q, d_payload);
   PCD_HIP_TRY(hipGetLastError());
   return PCD_OK;

@@ -3,7 +3,8 @@
 //
 // HBM layout (all hipMalloc'ed on one device):
 //   pts4 [n]   float4 {x,y,z,0}     original (post-NaN-filter) row order  -- epilogue gathers, brute force
-//   nrm4 [n]   float4 {nx,ny,nz,0}  original order                        -- epilogue gathers winners only
+//   pn8  [n]   2 x float4 {x,y,z,0, nx,ny,nz,0}  original order           -- epilogue gathers: a winner's point AND
+//                                   normal in ONE 32-byte record (one cache line instead of a line of pts4 and one of nrm4)
 //   sorted [m] float4 {x,y,z,bits(global_idx)}  finite rows in cell-sorted order (x fastest):
 //              one 16-B record per lane per load; a row of cells along x is one contiguous range
 //   cell_start [ncells+1] uint32    exclusive prefix of per-cell counts
@@ -69,7 +70,7 @@ struct pcd_cloud {
   // inverse over the whole cloud (0xFFFFFFFF = not a row of this shard).  Empty: global = index_base + i * index_stride.
   pcd::DevBuf<uint32_t> row_index, g2l;
   uint64_t g2l_n = 0;
-  pcd::DevBuf<float4> pts4, nrm4, sorted;
+  pcd::DevBuf<float4> pts4, pn8, sorted;   // pn8: 2 float4 per row
   pcd::DevBuf<uint32_t> cell_start;
   pcd::DevBuf<float> blk_aabb;
   pcd::GridParams grid{};

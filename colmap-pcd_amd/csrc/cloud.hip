@@ -27,7 +27,7 @@ __global__ void k_flag_rows(const float* __restrict__ xyz, const float* __restri
 
 __global__ void k_compact_rows(const float* __restrict__ xyz, const float* __restrict__ nrm, uint64_t n, int layout,
                                int raw_frame, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ pos,
-                               float4* __restrict__ pts4, float4* __restrict__ nrm4) {
+                               float4* __restrict__ pts4, float4* __restrict__ pn8) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t dst = (uint32_t)i;
@@ -46,7 +46,8 @@ __global__ void k_compact_rows(const float* __restrict__ xyz, const float* __res
     b = make_float4(q[0], q[1], q[2], 0.f);
   }
   pts4[dst] = a;
-  nrm4[dst] = b;
+  pn8[2 * (size_t)dst] = a;
+  pn8[2 * (size_t)dst + 1] = b;
 }
 
 __device__ inline int f2ord(float f) {
@@ -464,10 +465,10 @@ pcd_status pcd::cloud_create_indexed(const float* xyz, const float* nrm, uint64_
   }
   c->n = kept;
   if ((st = c->pts4.reserve(std::max<uint64_t>(kept, 1))) != PCD_OK) return fail(st);
-  if ((st = c->nrm4.reserve(std::max<uint64_t>(kept, 1))) != PCD_OK) return fail(st);
+  if ((st = c->pn8.reserve(2 * std::max<uint64_t>(kept, 1))) != PCD_OK) return fail(st);
   if (n)
     hipLaunchKernelGGL(k_compact_rows, dim3(div_up(n, 256)), dim3(256), 0, s, d_xyz.p, d_nrm.p, n, o.layout,
-                       o.raw_lidar_frame, keep.p, pos.p, c->pts4.p, c->nrm4.p);
+                       o.raw_lidar_frame, keep.p, pos.p, c->pts4.p, c->pn8.p);
   if (hipStreamSynchronize(s) != hipSuccess) { set_error("row transform failed"); return fail(PCD_ERR_HIP); }
   if ((st = build_grid(c, o.cell_size, s)) != PCD_OK) return fail(st);
   c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -504,14 +505,14 @@ pcd_status pcd_cloud_get_info(const pcd_cloud* c, pcd_cloud_info* info) {
 pcd_status pcd_cloud_download(const pcd_cloud* c, float* xyz, float* nrm) {
   PCD_REQUIRE(c, "null cloud");
   PCD_HIP_TRY(hipSetDevice(c->device));
-  std::vector<float4> h(c->n);
+  std::vector<float4> h(2 * c->n);
   if (xyz && c->n) {
     PCD_HIP_TRY(hipMemcpy(h.data(), c->pts4.p, c->n * sizeof(float4), hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < c->n; ++i) { xyz[3 * i] = h[i].x; xyz[3 * i + 1] = h[i].y; xyz[3 * i + 2] = h[i].z; }
   }
   if (nrm && c->n) {
-    PCD_HIP_TRY(hipMemcpy(h.data(), c->nrm4.p, c->n * sizeof(float4), hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < c->n; ++i) { nrm[3 * i] = h[i].x; nrm[3 * i + 1] = h[i].y; nrm[3 * i + 2] = h[i].z; }
+    PCD_HIP_TRY(hipMemcpy(h.data(), c->pn8.p, 2 * c->n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < c->n; ++i) { nrm[3 * i] = h[2 * i + 1].x; nrm[3 * i + 1] = h[2 * i + 1].y; nrm[3 * i + 2] = h[2 * i + 1].z; }
   }
   return PCD_OK;
 }

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_proj_splat(const ProjImageDev* __restri
 
 __global__ void k_proj_readout(const ProjImageDev* __restrict__ imgs, const double* __restrict__ feat_xy,
                                double scale, const uint64_t* __restrict__ zbuf, const float4* __restrict__ sorted,
-                               const float4* __restrict__ pts4, const float4* __restrict__ nrm4,
+                               const float4* __restrict__ pn8,
                                uint8_t* __restrict__ found, uint32_t* __restrict__ index, float* __restrict__ dist,
                                double* __restrict__ l6, double* __restrict__ cam_xyz) {
   const uint32_t ii = blockIdx.y;
@@ -315,7 +315,7 @@ __global__ void k_proj_readout(const ProjImageDev* __restrict__ imgs, const doub
     if (ok) {
       idx = __float_as_uint(sorted[(uint32_t)key].w);
       d = __uint_as_float((uint32_t)(key >> 32));
-      const float4 p = pts4[idx], nn = nrm4[idx];
+      const float4 p = pn8[2 * (size_t)idx], nn = pn8[2 * (size_t)idx + 1];
       o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = nn.x; o[4] = nn.y; o[5] = nn.z;
       // pcd_projection.cc:183-205
       const double fx = im.prm[0], fy = im.prm[1], cx = im.prm[2], cy = im.prm[3];
@@ -650,7 +650,7 @@ pcd_status pcd_proj_set_new_images(pcd_proj* p, uint64_t n_images, const pcd_pro
     if (maxf) {
       ScopedKernelTimer t("proj_readout", s);
       hipLaunchKernelGGL(k_proj_readout, dim3(fblocks, ni), dim3(256), 0, s, p->d_imgs.p, p->d_feat.p, pc.scale,
-                         p->zbuf.p, p->sorted.p, p->cloud->pts4.p, p->cloud->nrm4.p, p->o_found.p, p->o_index.p,
+                         p->zbuf.p, p->sorted.p, p->cloud->pn8.p, p->o_found.p, p->o_index.p,
                          p->o_dist.p, p->o_l6.p, p->o_cam.p);
     }
     PCD_HIP_TRY(hipGetLastError());
