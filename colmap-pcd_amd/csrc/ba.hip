@@ -947,6 +947,7 @@ static unsigned cost_blocks(const pcd_ba* b, bool want_blocks) {
 extern "C" {
 
 pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(d && out, "null pointer");
   *out = nullptr;
   PCD_REQUIRE(d->num_cameras > 0 && d->cam_model && d->cam_param_offset && d->cam_params, "cameras");
@@ -1094,6 +1095,7 @@ pcd_status pcd_ba_create(const pcd_ba_desc* d, pcd_ba** out) {
   if ((s1 = b->cost.reserve(1)) != PCD_OK) return fail(s1);
   *out = b;
   return PCD_OK;
+  });
 }
 
 void pcd_ba_destroy(pcd_ba* b) {

@@ -391,7 +391,9 @@ void pcd_cloud_options_default(pcd_cloud_options* o) {
 
 pcd_status pcd_cloud_create(const float* xyz, const float* nrm, uint64_t n, const pcd_cloud_options* opts,
                             pcd_cloud** out) {
+  return pcd::guard([&]() -> pcd_status {
   return pcd::cloud_create_indexed(xyz, nrm, n, opts, nullptr, 0, out);
+  });
 }
 
 }  // extern "C"
@@ -503,6 +505,7 @@ pcd_status pcd_cloud_get_info(const pcd_cloud* c, pcd_cloud_info* info) {
 }
 
 pcd_status pcd_cloud_download(const pcd_cloud* c, float* xyz, float* nrm) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(c, "null cloud");
   PCD_HIP_TRY(hipSetDevice(c->device));
   std::vector<float4> h(2 * c->n);
@@ -515,6 +518,7 @@ pcd_status pcd_cloud_download(const pcd_cloud* c, float* xyz, float* nrm) {
     for (uint64_t i = 0; i < c->n; ++i) { nrm[3 * i] = h[2 * i + 1].x; nrm[3 * i + 1] = h[2 * i + 1].y; nrm[3 * i + 2] = h[2 * i + 1].z; }
   }
   return PCD_OK;
+  });
 }
 
 }  // extern "C"

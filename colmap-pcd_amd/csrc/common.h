@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <exception>
+#include <new>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdint>
@@ -17,6 +20,24 @@ namespace pcd {
 
 // ----------------------------------------------------------------- errors --
 void set_error(const char* fmt, ...);
+
+// pcdhip.h promises that no entry point throws: the ones that allocate host memory (std::vector, new) run their body
+// inside guard(), which turns std::bad_alloc into PCD_ERR_OOM and anything else into PCD_ERR_INVALID.
+template <typename F>
+inline pcd_status guard(F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    set_error("host memory allocation failed");
+    return PCD_ERR_OOM;
+  } catch (const std::exception& e) {
+    set_error("unexpected exception: %s", e.what());
+    return PCD_ERR_INVALID;
+  } catch (...) {
+    set_error("unexpected exception");
+    return PCD_ERR_INVALID;
+  }
+}
 const char* get_error();
 
 #define PCD_HIP_TRY(expr)                                                              \

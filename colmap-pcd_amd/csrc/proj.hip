@@ -525,6 +525,7 @@ void pcd_proj_default_options(pcd_proj_options* o) {
 }
 
 pcd_status pcd_proj_create(pcd_cloud* cloud, const pcd_proj_options* options, pcd_proj** out) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(cloud && options && out, "null pointer");
   PCD_REQUIRE(options->submap_length > 0 && options->submap_width > 0 && options->submap_height > 0, "submap size");
   PCD_REQUIRE(options->depth_image_scale > 0, "depth_image_scale");
@@ -541,6 +542,7 @@ pcd_status pcd_proj_create(pcd_cloud* cloud, const pcd_proj_options* options, pc
   }
   *out = p;
   return PCD_OK;
+  });
 }
 
 void pcd_proj_destroy(pcd_proj* p) {
@@ -568,6 +570,7 @@ pcd_status pcd_proj_scale_coeffs(pcd_proj* p, int set, double* coeffs4, int* lat
 pcd_status pcd_proj_set_new_images(pcd_proj* p, uint64_t n_images, const pcd_proj_image* images, uint64_t n_feat,
                                    const double* feat_xy, uint8_t* found, uint32_t* lidar_index, float* dist,
                                    double* lidar6, double* cam_xyz) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(p, "null pointer");
   if (n_images == 0) return PCD_OK;
   PCD_REQUIRE(images, "null images");
@@ -670,6 +673,7 @@ pcd_status pcd_proj_set_new_images(pcd_proj* p, uint64_t n_images, const pcd_pro
   PCD_HIP_TRY(back(cam_xyz, p->o_cam.p, 3 * n_feat * 8));
   PCD_HIP_TRY(hipStreamSynchronize(s));
   return PCD_OK;
+  });
 }
 
 }  // extern "C"

@@ -20,6 +20,7 @@
 // buffers) or, with NULL callbacks, the library's own: peer copies to the first shard's device, one kernel, copies back.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 
 #include "cloud.h"
@@ -160,6 +161,7 @@ extern "C" {
 
 pcd_status pcd_cloud_create_sharded(const float* xyz, const float* nrm, uint64_t n, const pcd_cloud_options* opts,
                                     const int* devices, int ndev, pcd_cloud_shards** out) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(out, "out is null");
   *out = nullptr;
   PCD_REQUIRE(devices && ndev >= 1 && ndev <= 64, "devices / ndev");
@@ -244,6 +246,7 @@ pcd_status pcd_cloud_create_sharded(const float* xyz, const float* nrm, uint64_t
   }
   *out = sh;
   return PCD_OK;
+  });
 }
 
 void pcd_cloud_shards_destroy(pcd_cloud_shards* sh) {
@@ -264,6 +267,7 @@ pcd_cloud* pcd_cloud_shards_get(pcd_cloud_shards* sh, int s) {
 
 pcd_status pcd_nn_query_sharded(pcd_cloud_shards* sh, const double* q_xyz, uint64_t Q, const pcd_shard_reduce* red,
                                 uint32_t* idx, float* sqdist, uint8_t* found) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(sh && !sh->shard.empty(), "null shards");
   PCD_REQUIRE(Q == 0 || (q_xyz && idx && sqdist && found), "null pointer");
   if (Q == 0) return PCD_OK;
@@ -281,11 +285,13 @@ pcd_status pcd_nn_query_sharded(pcd_cloud_shards* sh, const double* q_xyz, uint6
     found[i] = f ? 1 : 0;
   }
   return PCD_OK;
+  });
 }
 
 pcd_status pcd_associate_sharded(pcd_cloud_shards* sh, const double* q_xyz, uint64_t Q, const double* max_range,
                                  uint64_t max_range_count, int gate_mode, const pcd_shard_reduce* red,
                                  const pcd_assoc_out* out) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(sh && !sh->shard.empty() && out, "null pointer");
   gate_mode &= ~PCD_GATE_BOUNDED_SEARCH;   // the sharded search is the exact unbounded one
   PCD_REQUIRE(gate_mode >= 0 && gate_mode <= 2, "gate_mode");
@@ -334,6 +340,7 @@ pcd_status pcd_associate_sharded(pcd_cloud_shards* sh, const double* q_xyz, uint
     }
   }
   return PCD_OK;
+  });
 }
 
 }  // extern "C"

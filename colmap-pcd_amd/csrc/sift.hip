@@ -805,6 +805,7 @@ extern "C" {
 pcd_status pcd_sift_match_device(int device, const uint8_t* d_desc1, int n1, const uint8_t* d_desc2, int n2,
                                  float max_ratio, float max_distance, int cross_check, int32_t* d_m12,
                                  int32_t* d_m21, uint32_t* d_matches, int32_t* d_num_matches, void* stream) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(n1 >= 0 && n2 >= 0 && d_num_matches, "sizes / count pointer");
   PCD_TRY(require_device(device));
   hipStream_t s = (hipStream_t)stream;
@@ -824,10 +825,12 @@ pcd_status pcd_sift_match_device(int device, const uint8_t* d_desc1, int n1, con
                                     d_matches, d_num_matches, *g_sift[device], s);
   PCD_TRY(sift_end_use(*g_sift[device], s));
   return st;
+  });
 }
 
 pcd_status pcd_sift_match(int device, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float max_ratio,
                           float max_distance, int cross_check, uint32_t* matches, int32_t* num_matches) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(num_matches && n1 >= 0 && n2 >= 0, "sizes / count pointer");
   *num_matches = 0;
   if (n1 == 0 || n2 == 0) return PCD_OK;
@@ -853,6 +856,7 @@ pcd_status pcd_sift_match(int device, const uint8_t* desc1, int n1, const uint8_
   if (cnt) PCD_HIP_TRY(hipMemcpy(matches, sc->matches.p, 2 * (size_t)cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
   *num_matches = cnt;
   return PCD_OK;
+  });
 }
 
 
@@ -860,6 +864,7 @@ pcd_status pcd_sift_match_batch_device(int device, const uint8_t* d_arena, const
                                        const uint32_t* pairs, int n_pairs, float max_ratio, float max_distance,
                                        int cross_check, uint32_t* d_matches, const uint64_t* match_offset,
                                        int32_t* d_counts, void* stream) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(n_images >= 0 && n_pairs >= 0 && first_row, "sizes / first_row");
   if (n_pairs == 0) return PCD_OK;
   PCD_REQUIRE(pairs && match_offset && d_counts && d_matches, "null pointer");
@@ -875,11 +880,13 @@ pcd_status pcd_sift_match_batch_device(int device, const uint8_t* d_arena, const
                                           (hipStream_t)stream);
   PCD_TRY(sift_end_use(*g_sift[device], (hipStream_t)stream));
   return st;
+  });
 }
 
 pcd_status pcd_sift_match_batch(int device, const uint8_t* arena, const uint64_t* first_row, int n_images,
                                 const uint32_t* pairs, int n_pairs, float max_ratio, float max_distance, int cross_check,
                                 uint32_t* matches, uint64_t matches_capacity, uint64_t* list_offset) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(n_images >= 0 && n_pairs >= 0 && first_row && list_offset, "sizes / first_row / list_offset");
   list_offset[0] = 0;
   if (n_pairs == 0) return PCD_OK;
@@ -925,6 +932,7 @@ pcd_status pcd_sift_match_batch(int device, const uint8_t* arena, const uint64_t
   PCD_HIP_TRY(hipGetLastError());
   PCD_HIP_TRY(hipMemcpy(matches, sc->dense.p, 2 * total * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return PCD_OK;
+  });
 }
 // ---- matcher handle: two descriptor slots resident on the device (SiftMatchGPU's usage pattern) ----
 }  // extern "C"
@@ -941,6 +949,7 @@ struct pcd_sift_matcher {
 extern "C" {
 
 pcd_status pcd_sift_matcher_create(int device, int max_sift, pcd_sift_matcher** out) {
+  return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(out && max_sift > 0, "null pointer / max_sift");
   PCD_REQUIRE(device >= 0 && device < 64, "device ordinal");
   PCD_TRY(require_device(device));
@@ -949,6 +958,7 @@ pcd_status pcd_sift_matcher_create(int device, int max_sift, pcd_sift_matcher** 
   m->max_sift = max_sift;
   *out = m;
   return PCD_OK;
+  });
 }
 
 void pcd_sift_matcher_destroy(pcd_sift_matcher* m) {
