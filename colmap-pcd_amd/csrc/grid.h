@@ -92,7 +92,7 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t k) {
 __device__ __forceinline__ int wave_argmin_u32(uint32_t v, unsigned long long mask) {
   const bool in = (mask >> (threadIdx.x & 63)) & 1ull;
   const uint32_t m = wave_min_u32(in ? v : 0xFFFFFFFFu);
-  const unsigned long long hit = __ballot(in && v == m);
+  const unsigned long long hit = __builtin_amdgcn_ballot_w64(v == m) & mask;   // (one v_cmp + s_and: no select round trip)
   return __ffsll((long long)(hit ? hit : mask)) - 1;
 }
 

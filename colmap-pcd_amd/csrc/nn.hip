@@ -796,8 +796,10 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
       const uint32_t id = (uint32_t)dm.w + (in ? (uint32_t)((cz * dm.y + cy) * dm.x + cx) : 0u); /* < 2^32 nodes */   \
       const float4 lo = *reinterpret_cast<const float4*>(aabb + 8 * (size_t)id);     /* lo.x lo.y lo.z hi.x */        \
       const float4 hi = *reinterpret_cast<const float4*>(aabb + 8 * (size_t)id + 4); /* hi.y hi.z start count */      \
-      const float px = fminf(fmaxf(qx, lo.x), lo.w), pyc = fminf(fmaxf(qy, lo.y), hi.x),                              \
-                  pz = fminf(fmaxf(qz, lo.z), hi.y);                                                                  \
+      /* clamp(q, lo, hi) = the median of the three for lo <= hi: ONE v_med3_f32 (fminf(fmaxf()) costs two ops + */     \
+      /* three canonicalising v_max x, x, x); an empty node's inverted box is masked below */                         \
+      const float px = __builtin_amdgcn_fmed3f(qx, lo.x, lo.w), pyc = __builtin_amdgcn_fmed3f(qy, lo.y, hi.x),        \
+                  pz = __builtin_amdgcn_fmed3f(qz, lo.z, hi.y);                                                       \
       const float lbv = l2_simple3(qx, qy, qz, px, pyc, pz);                                                          \
       cur_lb = (in && lo.x <= lo.w) ? lbv : INFINITY; /* empty nodes have an inverted box */                          \
       rs = __float_as_uint(hi.z); rn = __float_as_uint(hi.w); /* leaves carry their range */                          \
