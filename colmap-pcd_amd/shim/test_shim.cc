@@ -16,6 +16,7 @@
 #include "ceres_adapter.h"
 #include "pose_reader.h"
 #include "sift_match_hip.h"
+#include "exhaustive_matcher_hip.h"
 #include "lidar_hip.h"
 
 using namespace colmap_hip;
@@ -407,6 +408,76 @@ static int TestGpuSiftMatcher() {
   return 0;
 }
 
+// ExhaustiveFeatureMatcher::Run's block enumeration (feature/matching.cc:921-953): every unordered pair exactly once,
+// num_blocks^2 lists, at most block_size^2 pairs per list
+static void TestExhaustiveBlocks() {
+  for (const auto& cfg : std::vector<std::pair<size_t, size_t>>{{1, 50}, {2, 50}, {23, 5}, {50, 50}, {51, 50}, {120, 50}, {450, 50}}) {
+    const size_t n = cfg.first, B = cfg.second;
+    std::vector<image_t> ids(n);
+    for (size_t i = 0; i < n; ++i) ids[i] = (image_t)(100 + 3 * i);   // image ids are not positions
+    const auto blocks = ExhaustiveBlocks(ids, B);
+    const size_t nb = (n + B - 1) / B;
+    CHECK_EQ(blocks.size(), nb * nb);
+    std::vector<uint8_t> seen(n * n, 0);
+    size_t total = 0;
+    for (const auto& pairs : blocks) {
+      CHECK(pairs.size() <= B * B);
+      for (const auto& pr : pairs) {
+        const size_t a = (pr.first - 100) / 3, b = (pr.second - 100) / 3;
+        CHECK(a != b && a < n && b < n);
+        CHECK(!seen[a * n + b] && !seen[b * n + a]);
+        seen[a * n + b] = 1;
+        ++total;
+      }
+    }
+    CHECK_EQ(total, n * (n - 1) / 2);
+  }
+}
+
+// SiftFeatureMatcher::Match(image_pairs) for a block in one batched call == the SiftMatchGPU-shaped matcher pair by pair
+static int TestGpuSiftBlockMatcher() {
+  std::mt19937 rng(17);
+  const int n_img = 7;
+  const int sizes[n_img] = {300, 0, 129, 1, 511, 256, 77};
+  std::vector<std::vector<uint8_t>> desc(n_img);
+  std::vector<uint8_t> pool(600 * 128);
+  for (auto& v : pool) v = (uint8_t)(rng() % 64);
+  for (int i = 0; i < n_img; ++i) {
+    desc[i].resize((size_t)sizes[i] * 128);
+    for (int r = 0; r < sizes[i]; ++r) {
+      const int src = (int)(rng() % 600);
+      for (int k = 0; k < 128; ++k) desc[i][(size_t)r * 128 + k] = (uint8_t)std::min(255, pool[(size_t)src * 128 + k] + (int)(rng() % 3));
+    }
+  }
+  std::vector<image_t> ids;
+  for (int i = 0; i < n_img; ++i) ids.push_back((image_t)(10 + i));
+  SiftBlockOptions opt;
+  opt.max_ratio = 0.95; opt.max_distance = 1.2;
+  SiftBlockMatcherHIP block(opt);
+  auto get = [&](image_t id) { return SiftBlockMatcherHIP::Descriptors(desc[id - 10].data(), (uint32_t)sizes[id - 10]); };
+  size_t total = 0;
+  for (const auto& pairs : ExhaustiveBlocks(ids, 4)) {
+    std::vector<SiftBlockMatcherHIP::FeatureMatches> res;
+    CHECK(block.Match(pairs, get, &res));
+    CHECK_EQ(res.size(), pairs.size());
+    for (size_t p = 0; p < pairs.size(); ++p) {
+      const int a = (int)pairs[p].first - 10, b = (int)pairs[p].second - 10;
+      SiftMatchHIP m(4096);
+      CHECK(m.VerifyContextGL());
+      m.SetDescriptors(0, sizes[a], desc[a].data());
+      m.SetDescriptors(1, sizes[b], desc[b].data());
+      std::vector<uint32_t> buf(2 * (size_t)std::max(sizes[a], 1));
+      const int k = m.GetSiftMatch(std::max(sizes[a], 1), reinterpret_cast<uint32_t(*)[2]>(buf.data()), (float)opt.max_distance,
+                                   (float)opt.max_ratio, 1);
+      CHECK_EQ((size_t)std::max(k, 0), res[p].size());
+      for (int j = 0; j < k; ++j) CHECK(res[p][j].first == buf[2 * j] && res[p][j].second == buf[2 * j + 1]);
+      total += res[p].size();
+    }
+  }
+  CHECK(total > 100);
+  return 0;
+}
+
 // PcdProj mirror: wall z = 10 m in front of a camera at the origin (pinhole 3039 px, 4032 x 3024)
 static int TestGpuProjection() {
   std::vector<float> xyz, nrm;
@@ -779,7 +850,8 @@ static int TestGpu() {
   for (double r : res) s += r * r;
   CHECK(std::fabs(cost - 0.5 * s) <= 1e-9 * cost);
   CHECK(cost > 0 && cost < 300 * 8.0 + 1e4);   // +-2 px noise on 300 observations + one lidar term
-  return TestGpuProjection() + TestGpuSiftMatcher() + TestGpuCeresAdapterEndToEnd() + TestGpuShardedCloud();
+  return TestGpuProjection() + TestGpuSiftMatcher() + TestGpuSiftBlockMatcher() + TestGpuCeresAdapterEndToEnd() +
+         TestGpuShardedCloud();
 }
 
 int main(int argc, char** argv) {
@@ -796,6 +868,7 @@ int main(int argc, char** argv) {
   TestPoseReader();
   TestMatchVariablePoint();
   TestCeresBlockShapes();
+  TestExhaustiveBlocks();
   if (argc > 1 && std::strcmp(argv[1], "--gpu") == 0) g_fail += TestGpu();
   std::printf(g_fail ? "%d FAILED\n" : "ALL OK\n", g_fail);
   return g_fail ? 1 : 0;
