@@ -11,15 +11,14 @@
 // so the bytes are re-centred to int8 (a ^ 0x80) and fed to v_mfma_i32_32x32x32_i8 (K = 32 per
 // instruction, int32 accumulate: exact), the row-sum correction is added in the epilogue.
 //
-// k_sift_scores: one 128 x 128 score tile per workgroup (4 wavefronts, 64 x 64 each).  Both sets' tiles
-// (128 rows x 128 B) are staged once in LDS (144-B row pitch: conflict-free ds_read_b128 fragments).  The
-// tile is computed TWICE from the same fragments, as A.B^T and as B.A^T: in the MFMA result layout a lane
-// owns one column and 16 rows per 32x32 block, so the best / second-best scan over the *other* set is a
-// register-local loop in both directions (no cross-lane top-2 reductions, no score matrix in memory) --
-// 32 extra MFMAs per wavefront are cheaper than 64 shuffled reductions.  Per tile and direction one
-// (best, second, argbest) triple per descriptor goes to a partial buffer; k_sift_finalize merges the
-// partials in ascending tile order (ties -> first index, as the reference's ascending strict-> scan),
-// applies acos / max_distance / max_ratio; the cross check and the ordered compaction follow.
+// Default scores kernel: sift_stripe (k_sift_scores_stripe / k_sift_scores_batch, below): a persistent row-stripe walk
+// that multiplies every tile ONCE -- the column-direction top-2 is register-local in the MFMA result layout, the
+// row-direction top-2 is a running per-lane state over the whole walk that is merged across lanes once at the end.
+// k_sift_scores (PCD_SIFT_TILE=1, kept for A/B): the first design, one 128 x 128 score tile per workgroup, every tile
+// computed TWICE from the same fragments (A.B^T and B.A^T) so that both scans are register-local.
+// Per tile (or chunk) and direction one (best, second, argbest) triple per descriptor goes to a partial buffer;
+// k_sift_finalize merges the partials in ascending order (ties -> first index, as the reference's ascending strict->
+// scan), applies acos / max_distance / max_ratio; the cross check and the ordered compaction follow.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
