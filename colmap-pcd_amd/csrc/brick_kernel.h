@@ -10,9 +10,9 @@
 //     instructions are that one address + 0 / 16 / 32 / 48 bytes of immediate offset;
 //   * staging is LDS-DMA (global_load_lds_dwordx4: one 16-B record per lane, no VGPR round trip);
 //     the 4 DMAs of tile t+1 are in flight while tile t is compared (counted s_waitcnt vmcnt(4));
-//   * compare: lanes = staged points (ds_read_b128), the G queries are wave-uniform (SGPRs), every
-//     point is tested against every query with FLANN's float arithmetic, per-lane running minima of
-//     the packed (distance, index) keys;
+//   * compare: lanes = staged points (ds_read_b128), the G queries are wave-uniform (copied from SGPRs to VGPRs once
+//     per item: an SGPR operand halves the VALU rate on gfx950), every point is tested against every query with
+//     FLANN's float arithmetic, per-lane running minima of the packed (distance, index) keys (one v_min_f64 each);
 //   * one transposed butterfly reduces all G per-lane minima at once (reduce-scatter over
 //     xor 32/16/8, then xor 4/2/1), instead of G separate wavefront reductions;
 //   * work items are software-pipelined: the item record of group k+2 and the query / row-range

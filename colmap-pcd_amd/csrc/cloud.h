@@ -11,7 +11,8 @@
 //   blk_aabb [nodes][8] float       the AABB pyramid of the exact fallback.  Level 0 = LEAVES: every sub-block of
 //                                   2x2x2 cells -- an x-range of 2 cells of ONE quad row, i.e. one contiguous point
 //                                   range -- as {lo.xyz, hi.x | hi.y, hi.z, bits(first point), bits(count)}; level
-//                                   k+1 = 4x4x4 nodes of level k as {lo.xyz, hi.xyz, 0, 0}; the top level is one node.
+//                                   k+1 = 4x4x4 nodes of level k as {lo.xyz, hi.xyz, 0, 0}, up to the first level with <= 64 nodes
+//                                   (the walk starts at a virtual top over all of them, PyramidParams below).
 //                                   An expansion tests 64 children with the exact float bound; a leaf is scanned.
 #pragma once
 #include "common.h"

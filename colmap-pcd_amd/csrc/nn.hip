@@ -21,9 +21,14 @@
 //                    its distance to the boundary of the staged region.
 //   k_nn_fallback    one wavefront per remaining query: depth-first, nearest-first
 //                    descent of the 64-ary pyramid of tight AABBs over the grid
-//                    (level 0 = 4x4x4-cell blocks), the 64 children of a node one
-//                    per lane, pruned with the exact float lower bound.  Exact for
-//                    any query position, also outside the grid.
+//                    (level 0 = leaves of 2x2x2 cells, one contiguous point range each;
+//                    a virtual top over the first level with <= 64 nodes), the 64
+//                    children of a node one per lane, pruned with the exact float
+//                    lower bound.  Exact for any query position, also outside the grid.
+// Query bookkeeping in front of k_nn_brick: a two-level counting sort on the brick id
+// (k_bk_slots, k_bk_scatter, k_bk_count, k_bk_emit) that yields the brick-sorted query
+// records and the work items; queries with no cloud point in their brick's halo go
+// straight to the fallback list.
 //
 // Exactness of the pruning (float distances, not real ones):
 //   * AABB bound: lb = l2_simple3(q, clamp(q, lo, hi)) with lo/hi the actual
@@ -700,20 +705,8 @@ struct FbFused {   // inputs of k_nn_fallback<1 / 2> (the kernel as the only lau
   double fixed_range;
 };
 
-// scan the point range [s,e): lanes stride over it
-__device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, uint32_t s, uint32_t e, float qx,
-                                           float qy, float qz, uint64_t& lane_best) {
-  const int lane = threadIdx.x & 63;
-  for (uint32_t i = s + lane; i < e; i += 64) {
-    const float4 p = sorted[i];
-    const float d = l2_simple3(qx, qy, qz, p.x, p.y, p.z);
-    const uint64_t key = make_key(d, __float_as_uint(p.w));
-    lane_best = key < lane_best ? key : lane_best;
-  }
-}
-
-// One wavefront per query walks the 64-ary AABB pyramid over the grid (level 0 = 4x4x4-cell blocks,
-// level k+1 = 4x4x4 nodes of level k): the 64 children of the current node sit one per lane, each
+// One wavefront per query walks the 64-ary AABB pyramid over the grid (level 0 = 2x2x2-cell leaves carrying their
+// point range, level k+1 = 4x4x4 nodes of level k, cloud.h): the 64 children of the current node sit one per lane, each
 // lane computes the exact float lower bound of its child, and the wave descends into the nearest
 // child whose bound does not exceed the best distance so far (depth first, nearest first).
 // Every skipped subtree has bound > best, so the result is the exact minimum of the packed keys.
