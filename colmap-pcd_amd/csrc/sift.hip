@@ -14,9 +14,9 @@
 // Default scores kernel: sift_stripe (k_sift_scores_stripe / k_sift_scores_batch, below): a persistent row-stripe walk
 // that multiplies every tile ONCE -- the column-direction top-2 is register-local in the MFMA result layout, the
 // row-direction top-2 is a running per-lane state over the whole walk that is merged across lanes once at the end.
-// k_sift_scores (PCD_SIFT_TILE=1, kept for A/B): the first design, one 128 x 128 score tile per workgroup, every tile
-// computed TWICE from the same fragments (A.B^T and B.A^T) so that both scans are register-local.
-// Per tile (or chunk) and direction one (best, second, argbest) triple per descriptor goes to a partial buffer;
+// (Rounds 1-2 multiplied every tile twice, A.B^T and B.A^T, so that both scans were register-local.)
+// Per chunk / 64-row group and direction one (best, second, argbest) triple per descriptor goes to a partial buffer
+// (column direction: 8 bytes, the two packed scan values as they are; k_sift_finalize decodes them);
 // k_sift_finalize merges the partials in ascending order (ties -> first index, as the reference's ascending strict->
 // scan), applies acos / max_distance / max_ratio; the cross check and the ordered compaction follow.
 #include <algorithm>
@@ -75,125 +75,6 @@ __device__ __forceinline__ void top2_merge(int b2, int s2, int a2, int& best, in
   second = nsecond;
 }
 
-// part12 [n1][nbx] / part21 [n2][nby] int4 {best, second, arg, 0}
-__global__ __launch_bounds__(256) void k_sift_scores(const uint8_t* __restrict__ d1, int n1, const uint8_t* __restrict__ d2,
-                                                     int n2, const int* __restrict__ sum1, const int* __restrict__ sum2,
-                                                     int4* __restrict__ part12, int4* __restrict__ part21, int nbx,
-                                                     int nby) {
-  __shared__ __attribute__((aligned(16))) uint8_t sA[kSiftTile * kSiftPitch];
-  __shared__ __attribute__((aligned(16))) uint8_t sB[kSiftTile * kSiftPitch];
-  __shared__ int sSumA[kSiftTile], sSumB[kSiftTile];
-  __shared__ int2 sMerge[2][2][64];   // [direction][64-column half][column]: packed (best, second) of the upper row half
-  const int bx = blockIdx.x, by = blockIdx.y;           // bx: tile of set 2 (columns), by: tile of set 1 (rows)
-  const int row0 = by * kSiftTile, col0 = bx * kSiftTile;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  // ---- stage both tiles: 1024 16-B chunks each, re-centred to int8 ----
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int c = tid + it * 256, r = c >> 3, q = c & 7;
-    uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-    if (row0 + r < n1) va = *reinterpret_cast<const uint4*>(d1 + (size_t)(row0 + r) * 128 + q * 16);
-    if (col0 + r < n2) vb = *reinterpret_cast<const uint4*>(d2 + (size_t)(col0 + r) * 128 + q * 16);
-    va.x ^= 0x80808080u; va.y ^= 0x80808080u; va.z ^= 0x80808080u; va.w ^= 0x80808080u;
-    vb.x ^= 0x80808080u; vb.y ^= 0x80808080u; vb.z ^= 0x80808080u; vb.w ^= 0x80808080u;
-    *reinterpret_cast<uint4*>(sA + r * kSiftPitch + q * 16) = va;
-    *reinterpret_cast<uint4*>(sB + r * kSiftPitch + q * 16) = vb;
-  }
-  if (tid < kSiftTile) {
-    sSumA[tid] = row0 + tid < n1 ? sum1[row0 + tid] : 0;
-    sSumB[tid] = col0 + tid < n2 ? sum2[col0 + tid] : 0;
-  }
-  __syncthreads();
-
-  // ---- 64 x 64 per wavefront, both orientations from the same fragments ----
-  // The accumulators start at 128 * rowsum(row) (exact int32), so the scan below needs no per-element add.
-  v16i acc1[2][2], acc2[2][2];   // acc1[mt][nt]: rows = set-1, cols = set-2;  acc2[nt][mt]: rows = set-2, cols = set-1
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int rr = a * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
-      const int ra = 128 * sSumA[wr * 64 + rr], rb = 128 * sSumB[wc * 64 + rr];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) { acc1[a][c][k] = ra; acc2[a][c][k] = rb; }
-    }
-  const int lr = lane & 31, lh = lane >> 5;
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    v4i fa[2], fb[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      fa[t] = *reinterpret_cast<const v4i*>(sA + (wr * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
-      fb[t] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + t * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        acc1[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mt], fb[nt], acc1[mt][nt], 0, 0, 0);
-        acc2[nt][mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[nt], fa[mt], acc2[nt][mt], 0, 0, 0);
-      }
-  }
-
-  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-  // Direction 2 -> 1 (for every set-2 descriptor j the best set-1 rows): acc1, lane owns column j.
-  // The column constant 128*sum2[j] - 128^3 does not change the order inside a column, so the scan runs on the
-  // accumulators as they are and the constant is added back at the end.
-  // Packed scan: value = score << 8 | (255 - row in the 128-row tile).  Scores are < 2^23 in magnitude and the
-  // code is unique per row and larger for lower rows, so a signed max picks the higher score and, at equal
-  // scores, the lower row -- the reference's ascending strict-> scan (sift.cc:72-84) -- and the running second
-  // best is the median of (best, second, value): 3 VALU per score (shift-or, max, med3) and no index tracking.
-#pragma unroll
-  for (int dir = 0; dir < 2; ++dir) {
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {               // 32-column tile inside the wavefront's 64 columns
-      // dir 0: columns = set 2 (wc, nt = ct), rows = set 1 (wr, mt);  dir 1: columns = set 1 (wr, mt = ct), rows = set 2 (wc, nt)
-      const int ccol = (dir == 0 ? wc : wr) * 64 + ct * 32 + lr;            // column inside the 128 tile
-      const int cconst = 128 * (dir == 0 ? sSumB[ccol] : sSumA[ccol]) - kSiftConst;
-      const int other = dir == 0 ? wr : wc;          // which of the two 64-row halves this wavefront holds
-      const int colhalf = dir == 0 ? wc : wr;        // which 64-column half
-      const int init = (int)((unsigned)(-cconst) << 8);   // true score 0, code 0 = "no row" (sift.cc:66-68)
-      const unsigned code_base = 255u - (unsigned)(other * 64 + 4 * lh);
-      int best = init, second = init;
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const v16i& acc = dir == 0 ? acc1[rt][ct] : acc2[rt][ct];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const unsigned code = code_base - (unsigned)(rt * 32 + (reg & 3) + 8 * (reg >> 2));
-          const int v = (int)(((unsigned)acc[reg] << 8) | code);
-          int med;
-          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(med) : "v"(best), "v"(second), "v"(v));
-          second = med;
-          best = max(best, v);
-        }
-      }
-      // the two lane halves hold interleaved rows of the same column
-      {
-        const int b2 = __shfl_xor(best, 32), s2 = __shfl_xor(second, 32);
-        second = max(max(second, s2), min(best, b2));
-        best = max(best, b2);
-      }
-      // merge the two wavefronts that share these columns (dir 0: wr = 0,1; dir 1: wc = 0,1) through LDS
-      if (other == 1 && lh == 0) sMerge[dir][colhalf][ct * 32 + lr] = make_int2(best, second);
-      __syncthreads();
-      if (other == 0 && lh == 0) {
-        const int2 o = sMerge[dir][colhalf][ct * 32 + lr];
-        second = max(max(second, o.y), min(best, o.x));
-        best = max(best, o.x);
-        const int bs = (best >> 8) + cconst, ss = (second >> 8) + cconst;      // true scores (>= 0)
-        const int arg = bs > 0 ? (dir == 0 ? row0 : col0) + 255 - (best & 255) : -1;   // strict >: a zero score never matches
-        const int gcol = (dir == 0 ? col0 : row0) + ccol;
-        // partials are [tile][descriptor]: coalesced here and in the merge kernel
-        if (dir == 0) { if (gcol < n2) part21[(size_t)by * n2 + gcol] = make_int4(bs, ss, arg, 0); }
-        else { if (gcol < n1) part12[(size_t)bx * n1 + gcol] = make_int4(bs, ss, arg, 0); }
-      }
-      __syncthreads();
-    }
-  }
-}
-
 // ---- persistent row-stripe variant (round 3: ONE orientation) ----------------------------------------------------
 // Workgroup (by, chunk) owns the 128-row tile `by` of set 1 and walks `ct` column tiles of set 2 (staged through LDS,
 // the next tile fetched into registers while the current one is used; one __syncthreads per tile).  A wavefront owns
@@ -210,10 +91,12 @@ __global__ __launch_bounds__(256) void k_sift_scores(const uint8_t* __restrict__
 //     (row, lane-column-class) slots over the WHOLE walk; packed value = (acc << 8) + K, K = (column constant << 8) +
 //     (255 - block sequence number) is one VGPR per block, so the column constant costs nothing: 3 VALU per score.
 //     The 32 lanes that share a row are merged ONCE at the end of the walk, through LDS.
-// part12 [nchunk][n1], part21 [2 nby][n2], as before.  A chunk is at most 128 tiles (8-bit sequence code).
+// part12 [nchunk][n1] int4 {best, second, arg, 0}; part21 [2 nby][n2] int2 = the packed (best, second) of the column
+// scan, relative to the column constant (sift_finalize decodes: 8 bytes per partial instead of 16 -- the finalize
+// kernel is bound by reading them).  A chunk is at most 128 tiles (8-bit sequence code).
 __device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int n1, const uint8_t* __restrict__ d2,
                                             int n2, const int* __restrict__ sum1, const int* __restrict__ sum2,
-                                            int4* __restrict__ part12, int4* __restrict__ part21, int nbx,
+                                            int4* __restrict__ part12, int2* __restrict__ part21, int nbx,
                                             int ct_per_chunk, const int chunk, const int by) {
   __shared__ __attribute__((aligned(16))) uint8_t sB[2][kSiftTile * kSiftPitch];
   __shared__ int sSumB[2][kSiftTile];
@@ -324,10 +207,9 @@ __device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int 
       csec = max(max(csec, s2), min(cbest, b2));
       cbest = max(cbest, b2);
     }
-    const int bs = (cbest >> 8) + cc, ss = (csec >> 8) + cc;        // true scores (>= 0)
-    const int arg = bs > 0 ? row0 + wr * 64 + 68 - (cbest & 255) : -1;
+    // packed (score - column constant) << 8 | 68 - row in the 64-row group: decoded in sift_finalize
     const int gcol = bx * kSiftTile + wc * 64 + blk * 32 + lr;
-    if (lh == 0 && gcol < n2) part21[(size_t)(by * 2 + wr) * n2 + gcol] = make_int4(bs, ss, arg, 0);
+    if (lh == 0 && gcol < n2) part21[(size_t)(by * 2 + wr) * n2 + gcol] = make_int2(cbest, csec);
   };
 
   v16i acc0[2], acc1[2];
@@ -392,7 +274,7 @@ __device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int 
 __global__ __launch_bounds__(256, PCD_SIFT_WGS) void k_sift_scores_stripe(const uint8_t* __restrict__ d1, int n1,
                                                             const uint8_t* __restrict__ d2, int n2,
                                                             const int* __restrict__ sum1, const int* __restrict__ sum2,
-                                                            int4* __restrict__ part12, int4* __restrict__ part21,
+                                                            int4* __restrict__ part12, int2* __restrict__ part21,
                                                             int nbx, int ct_per_chunk) {
   sift_stripe(d1, n1, d2, n2, sum1, sum2, part12, part21, nbx, ct_per_chunk, blockIdx.x, blockIdx.y);
 }
@@ -402,7 +284,7 @@ __global__ __launch_bounds__(256, PCD_SIFT_WGS) void k_sift_scores_stripe(const 
 // extents are sized for the largest pair of the batch, smaller pairs leave early.
 struct SiftPairDev {
   uint32_t row1, n1, row2, n2;   // arena rows of the two images
-  uint64_t part12, part21;       // int4 offsets of the pair's partial results
+  uint64_t part12, part21;       // int4 / int2 offsets of the pair's partial results
   uint64_t m12, m21;             // int offsets of the pair's best-match arrays
   uint64_t match;                // offset (in matches) of the pair's output list
 };
@@ -410,7 +292,7 @@ struct SiftPairDev {
 __global__ __launch_bounds__(256, PCD_SIFT_WGS) void k_sift_scores_batch(const uint8_t* __restrict__ arena,
                                                            const int* __restrict__ sum,
                                                            const SiftPairDev* __restrict__ pairs,
-                                                           int4* __restrict__ part12, int4* __restrict__ part21,
+                                                           int4* __restrict__ part12, int2* __restrict__ part21,
                                                            int nchunk) {
   const SiftPairDev pr = pairs[blockIdx.z];
   const int nbx = ((int)pr.n2 + kSiftTile - 1) / kSiftTile, nby = ((int)pr.n1 + kSiftTile - 1) / kSiftTile;
@@ -423,7 +305,8 @@ __global__ __launch_bounds__(256, PCD_SIFT_WGS) void k_sift_scores_batch(const u
 // sift.cc:72-104: merge the per-tile triples in ascending tile order, then the distance / ratio tests.
 // One launch for both directions: threads [0, n1) finish set 1 -> 2, threads [n1, n1 + n2) set 2 -> 1.
 __device__ __forceinline__ void sift_finalize(const int4* __restrict__ part12, int n1, int nbx,
-                                              const int4* __restrict__ part21, int n2, int nby, float max_ratio,
+                                              const int2* __restrict__ part21, int n2, int nby,
+                                              const int* __restrict__ sum2, float max_ratio,
                                               float max_distance, int* __restrict__ m12, int* __restrict__ m21) {
   // 16 lanes per descriptor: lane p merges tiles p, p + 16, ... in ascending order, then a 4-step butterfly.
   // On equal best scores the lower index wins, which is the earlier tile (indices ascend with the tile) --
@@ -431,13 +314,21 @@ __device__ __forceinline__ void sift_finalize(const int4* __restrict__ part12, i
   const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, p = threadIdx.x & 15;
   if (g >= n1 + n2) return;
   const bool first = g < n1;
-  const int4* __restrict__ part = first ? part12 : part21;
-  const int n = first ? n1 : n2, nb = first ? nbx : nby;
   const int i = first ? g : g - n1;
   int best = 0, second = 0, arg = -1;
-  for (int b = p; b < nb; b += 16) {
-    const int4 v = part[(size_t)b * n + i];
-    top2_merge(v.x, v.y, v.z, best, second, arg);
+  if (first) {
+    for (int b = p; b < nbx; b += 16) {
+      const int4 v = part12[(size_t)b * n1 + i];
+      top2_merge(v.x, v.y, v.z, best, second, arg);
+    }
+  } else {
+    // column direction: partial b = the 64-row group b (rows 64 b ..); packed (score - cc) << 8 | 68 - row in the group
+    const int cc = 128 * sum2[i] - kSiftConst;
+    for (int b = p; b < nby; b += 16) {
+      const int2 v = part21[(size_t)b * n2 + i];
+      const int bs = (v.x >> 8) + cc, ss = (v.y >> 8) + cc;   // true scores (>= 0)
+      top2_merge(bs, ss, bs > 0 ? b * 64 + 68 - (v.x & 255) : -1, best, second, arg);
+    }
   }
 #pragma unroll
   for (int o = 1; o < 16; o <<= 1) {
@@ -458,22 +349,24 @@ __device__ __forceinline__ void sift_finalize(const int4* __restrict__ part12, i
 }
 
 __global__ __launch_bounds__(256) void k_sift_finalize(const int4* __restrict__ part12, int n1, int nbx,
-                                                       const int4* __restrict__ part21, int n2, int nby,
-                                                       float max_ratio, float max_distance, int* __restrict__ m12,
+                                                       const int2* __restrict__ part21, int n2, int nby,
+                                                       const int* __restrict__ sum2, float max_ratio,
+                                                       float max_distance, int* __restrict__ m12,
                                                        int* __restrict__ m21) {
-  sift_finalize(part12, n1, nbx, part21, n2, nby, max_ratio, max_distance, m12, m21);
+  sift_finalize(part12, n1, nbx, part21, n2, nby, sum2, max_ratio, max_distance, m12, m21);
 }
 
 __global__ __launch_bounds__(256) void k_sift_finalize_batch(const SiftPairDev* __restrict__ pairs,
+                                                             const int* __restrict__ sum,
                                                              const int4* __restrict__ part12,
-                                                             const int4* __restrict__ part21, int nchunk,
+                                                             const int2* __restrict__ part21, int nchunk,
                                                              float max_ratio, float max_distance, int* __restrict__ m12,
                                                              int* __restrict__ m21) {
   const SiftPairDev pr = pairs[blockIdx.z];
   const int nbx = ((int)pr.n2 + kSiftTile - 1) / kSiftTile, nby = ((int)pr.n1 + kSiftTile - 1) / kSiftTile;
   const int ct = max(1, (nbx + nchunk - 1) / nchunk), used = (nbx + ct - 1) / ct;   // chunks that wrote a partial
-  sift_finalize(part12 + pr.part12, (int)pr.n1, used, part21 + pr.part21, (int)pr.n2, 2 * nby, max_ratio, max_distance,
-                m12 + pr.m12, m21 + pr.m21);
+  sift_finalize(part12 + pr.part12, (int)pr.n1, used, part21 + pr.part21, (int)pr.n2, 2 * nby, sum + pr.row2, max_ratio,
+                max_distance, m12 + pr.m12, m21 + pr.m21);
 }
 
 // sift.cc:118-143 for n1 <= 1024 * kCompactPer: cross check, ordered compaction and count in ONE workgroup
@@ -573,7 +466,8 @@ __global__ void k_sift_compact(const int* __restrict__ m12, const uint32_t* __re
 struct SiftScratch {
   DevBuf<uint8_t> d1, d2;
   DevBuf<int> sum1, sum2, m12, m21, count;
-  DevBuf<int4> part12, part21;
+  DevBuf<int4> part12;
+  DevBuf<int2> part21;
   DevBuf<uint32_t> keep, pos, matches;
   DevBuf<char> tmp;
   // batch entry
@@ -598,7 +492,6 @@ struct SiftScratch {
   }
 };
 static SiftScratch* g_sift[64] = {nullptr};
-static int g_sift_tile_kernel = 0;   // 1 = one 128x128 tile per workgroup (the first design; A/B timing via PCD_SIFT_TILE=1)
 static std::recursive_mutex g_sift_mu;
 typedef std::lock_guard<std::recursive_mutex> SiftLock;
 
@@ -622,8 +515,6 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
                               float max_distance, int cross_check, int* d_m12, int* d_m21, uint32_t* d_matches,
                               int* d_count, SiftScratch& sc, hipStream_t s) {
   const int nby = (n1 + kSiftTile - 1) / kSiftTile, nbx = (n2 + kSiftTile - 1) / kSiftTile;
-  static const int tile_env = std::getenv("PCD_SIFT_TILE") ? std::atoi(std::getenv("PCD_SIFT_TILE")) : 0;
-  g_sift_tile_kernel = tile_env;
   // stripe walk: enough (row tile, chunk) workgroups to fill the chip twice over
   // (a chunk is at most 128 column tiles: the stripe kernel's 8-bit sequence code)
   // PCD_SIFT_NCHUNK (tests / fuzzing): force the number of column chunks, e.g. 1 = every stripe walks all tiles
@@ -634,7 +525,7 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
   const int ct_per_chunk = (nbx + nchunk - 1) / nchunk;
   const int nchunk_used = (nbx + ct_per_chunk - 1) / ct_per_chunk;
   PCD_TRY(sc.sum1.reserve(n1)); PCD_TRY(sc.sum2.reserve(n2));
-  PCD_TRY(sc.part12.reserve((size_t)n1 * std::max(nbx, nchunk_used))); PCD_TRY(sc.part21.reserve((size_t)n2 * nby * 2));
+  PCD_TRY(sc.part12.reserve((size_t)n1 * nchunk_used)); PCD_TRY(sc.part21.reserve((size_t)n2 * nby * 2));
   PCD_TRY(sc.keep.reserve(n1)); PCD_TRY(sc.pos.reserve(n1));
   {
     ScopedKernelTimer t("sift_rowsum", s);
@@ -643,18 +534,13 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
   }
   {
     ScopedKernelTimer t("sift_scores", s);
-    if (g_sift_tile_kernel)
-      hipLaunchKernelGGL(k_sift_scores, dim3(nbx, nby), dim3(256), 0, s, d_d1, n1, d_d2, n2, sc.sum1.p, sc.sum2.p,
-                         sc.part12.p, sc.part21.p, nbx, nby);
-    else
-      hipLaunchKernelGGL(k_sift_scores_stripe, dim3(nchunk_used, nby), dim3(256), 0, s, d_d1, n1, d_d2, n2, sc.sum1.p,
-                         sc.sum2.p, sc.part12.p, sc.part21.p, nbx, ct_per_chunk);
+    hipLaunchKernelGGL(k_sift_scores_stripe, dim3(nchunk_used, nby), dim3(256), 0, s, d_d1, n1, d_d2, n2, sc.sum1.p,
+                       sc.sum2.p, sc.part12.p, sc.part21.p, nbx, ct_per_chunk);
   }
   {
     ScopedKernelTimer t("sift_finalize", s);
     hipLaunchKernelGGL(k_sift_finalize, dim3(div_up(((uint64_t)n1 + n2) * 16, 256)), dim3(256), 0, s, sc.part12.p, n1,
-                       g_sift_tile_kernel ? nbx : nchunk_used, sc.part21.p, n2, g_sift_tile_kernel ? nby : 2 * nby,
-                       max_ratio, max_distance, d_m12, d_m21);
+                       nchunk_used, sc.part21.p, n2, 2 * nby, sc.sum2.p, max_ratio, max_distance, d_m12, d_m21);
   }
   {
     ScopedKernelTimer t("sift_compact", s);
@@ -745,7 +631,8 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
         if (n1 == 0 || n2 == 0) n1 = n2 = 0;   // an empty image: no matches (sift_test.cc:311-318); every kernel skips the pair
         const size_t nby = (n1 + kSiftTile - 1) / kSiftTile;
         const size_t need12 = (size_t)nchunk * n1, need21 = 2 * nby * n2;
-        if (p > p0 && (o12 + need12 + o21 + need21 > budget || p - p0 >= 65535)) break;
+        // (the budget counts 16-byte units: part12 entries are int4, part21 entries int2)
+        if (p > p0 && (o12 + need12 + (o21 + need21 + 1) / 2 > budget || p - p0 >= 65535)) break;
         tab[p] = SiftPairDev{(uint32_t)first_row[a], (uint32_t)n1, (uint32_t)first_row[b], (uint32_t)n2, o12, o21, om12, om21,
                              match_offset[p]};
         o12 += need12; o21 += need21; om12 += n1; om21 += n2;
@@ -783,7 +670,7 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
       {
         ScopedKernelTimer t("sift_finalize", s);
         hipLaunchKernelGGL(k_sift_finalize_batch, dim3(div_up((uint64_t)mxsum * 16, 256), 1, np), dim3(256), 0, s,
-                           sc.pairs.p + p0, sc.part12.p, sc.part21.p, nchunk, max_ratio, max_distance, sc.m12.p, sc.m21.p);
+                           sc.pairs.p + p0, sc.sum1.p, sc.part12.p, sc.part21.p, nchunk, max_ratio, max_distance, sc.m12.p, sc.m21.p);
       }
     }
     {
