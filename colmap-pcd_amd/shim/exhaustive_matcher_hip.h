@@ -24,23 +24,26 @@ using ImagePairs = std::vector<std::pair<image_t, image_t>>;
 // feature/matching.cc:921-953: blocks of `block_size` consecutive images; inside a block pair, (idx1, idx2) is taken
 // when (idx1 > idx2 && idx1 % B <= idx2 % B) || (idx1 < idx2 && idx1 % B < idx2 % B) -- every unordered pair once.
 inline std::vector<ImagePairs> ExhaustiveBlocks(const std::vector<image_t>& image_ids, size_t block_size) {
-  std::vector<ImagePairs> blocks;
-  if (block_size == 0) return blocks;
-  for (size_t start_idx1 = 0; start_idx1 < image_ids.size(); start_idx1 += block_size) {
-    const size_t end_idx1 = std::min(image_ids.size(), start_idx1 + block_size) - 1;
-    for (size_t start_idx2 = 0; start_idx2 < image_ids.size(); start_idx2 += block_size) {
-      const size_t end_idx2 = std::min(image_ids.size(), start_idx2 + block_size) - 1;
-      ImagePairs pairs;
-      for (size_t idx1 = start_idx1; idx1 <= end_idx1; ++idx1)
-        for (size_t idx2 = start_idx2; idx2 <= end_idx2; ++idx2) {
-          const size_t block_id1 = idx1 % block_size, block_id2 = idx2 % block_size;
-          if ((idx1 > idx2 && block_id1 <= block_id2) || (idx1 < idx2 && block_id1 < block_id2))
-            pairs.emplace_back(image_ids[idx1], image_ids[idx2]);
+  std::vector<ImagePairs> lists;
+  const size_t n = image_ids.size(), B = block_size;
+  if (B == 0) return lists;
+  const size_t nblocks = (n + B - 1) / B;
+  lists.reserve(nblocks * nblocks);
+  for (size_t bi = 0; bi < nblocks; ++bi)
+    for (size_t bj = 0; bj < nblocks; ++bj) {
+      const size_t i_end = std::min(n, (bi + 1) * B), j_end = std::min(n, (bj + 1) * B);
+      ImagePairs list;
+      for (size_t i = bi * B; i < i_end; ++i)
+        for (size_t j = bj * B; j < j_end; ++j) {
+          // position inside the block decides which of (i, j) / (j, i) is taken, so that each unordered pair of the
+          // two blocks -- and each pair inside a diagonal block -- appears in exactly one list
+          const size_t pi = i % B, pj = j % B;
+          const bool take = i > j ? pi <= pj : (i < j && pi < pj);
+          if (take) list.emplace_back(image_ids[i], image_ids[j]);
         }
-      blocks.push_back(std::move(pairs));
+      lists.push_back(std::move(list));
     }
-  }
-  return blocks;
+  return lists;
 }
 
 struct SiftBlockOptions {   // SiftMatchingOptions as far as the brute-force matcher reads them (feature/sift.h:118-150)
