@@ -224,9 +224,9 @@ __device__ __forceinline__ int item_count(const uint4 it) { return (int)(it.w >>
 __device__ __forceinline__ void brick_region(const GridParams& g, const BrickParams& b, const uint4 it, int c0[3],
                                              int c1[3]) {
   const int bx = (int)it.y, by = (int)it.z, bz = (int)(it.w & 0x0FFFFFFFu);
-  c0[0] = max(bx * b.Bx - b.R, 0); c0[1] = max(by * b.B - b.S - b.R, 0); c0[2] = max(bz * b.B - b.S - b.R, 0);
-  c1[0] = min(bx * b.Bx + b.Bx + b.R, g.dims[0]); c1[1] = min(by * b.B - b.S + b.B + b.R, g.dims[1]);
-  c1[2] = min(bz * b.B - b.S + b.B + b.R, g.dims[2]);
+  c0[0] = max(bx * b.Bx - b.R, 0); c0[1] = max(by * b.B - b.R, 0); c0[2] = max(bz * b.B - b.R, 0);
+  c1[0] = min(bx * b.Bx + b.Bx + b.R, g.dims[0]); c1[1] = min(by * b.B + b.B + b.R, g.dims[1]);
+  c1[2] = min(bz * b.B + b.B + b.R, g.dims[2]);
 }
 
 // Lane r < nrows gets the point range of quad row r of the region: the cells [c0,c1) of brick_region, grown in
@@ -263,15 +263,12 @@ template <int G>
 __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams g, BrickParams b, const float4* __restrict__ sorted,
                                                   const uint32_t* __restrict__ cell_start,
                                                   const float4* __restrict__ qsorted,
-                                                  uint64_t* __restrict__ ksorted,
+                                                  const uint64_t* __restrict__ ksorted,
                                                   const uint4* __restrict__ items, NnCounters* __restrict__ ctr,
                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ fb_list,
                                                   uint32_t* __restrict__ fb_count, int flags) {
-  // flags: bit 0 = collect statistics, bit 1 = a stencil stage follows (stencil_kernel.h, BRICK = 1): the unproven
-  // queries are listed by their POSITION in the brick-sorted arrays and their tentative key is left in ksorted
-  // (bits 8.. = ablations, only in -DPCD_ABLATE builds)
+  // flags: bit 0 = collect statistics (bits 8.. = ablations, only in -DPCD_ABLATE builds)
   const int collect_stats = flags & 1;
-  const bool by_position = (flags & 2) != 0;
   static_assert(G == 8, "the transposed reduction is written for 8 queries per group");
   __shared__ __attribute__((aligned(16))) float4 s_tile[4][2][kTile];
   const int lane = threadIdx.x & 63;
@@ -457,7 +454,6 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
       const double bd = (double)__uint_as_float((uint32_t)(mine >> 32));
       unproven = !(bd < bound) && !(flags & kAblateFallback);
       keys[my_qi] = mine;  // final, or the starting bound of the fallback
-      if (by_position && unproven) ksorted[it0.x + lane] = mine;
     }
     const unsigned long long um = __ballot(unproven);
     if (um) {
@@ -473,7 +469,7 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
         fb_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
         fb_left = kFbChunk;
       }
-      if (unproven) fb_list[fb_base + __popcll(um & ((1ull << lane) - 1))] = by_position ? it0.x + (uint32_t)lane : __float_as_uint(m0.q.w);
+      if (unproven) fb_list[fb_base + __popcll(um & ((1ull << lane) - 1))] = __float_as_uint(m0.q.w);
       fb_base += k;
       fb_left -= k;
     }

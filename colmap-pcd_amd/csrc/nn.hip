@@ -66,20 +66,18 @@ constexpr uint64_t kSmallBatch = 65536;
 // ------------------------------------------------------------ brick math ---
 struct BrickParams {
   int B, R;        // brick edge in cells (y, z), halo in cells
-  int S;           // bricks start S cells before the grid origin in y and z: brick b = cells [b B - S, b B - S + B).
-                   //   B = 2, R = 1, S = 1 puts the halo region [2b - 2, 2b + 2) on whole cell quads: 2 x 2 quad rows
   int Bx;          // brick length along x in cells (the rows of the region run along x)
   int nb[3];       // bricks per axis
   uint32_t nbricks;
 };
 
-static BrickParams make_bricks(const GridParams& g, int B, int Bx, int R, int S = 0) {
+static BrickParams make_bricks(const GridParams& g, int B, int Bx, int R) {
   BrickParams b;
-  b.B = B; b.R = R; b.Bx = Bx; b.S = S;
+  b.B = B; b.R = R; b.Bx = Bx;
   uint64_t n = 1;
   for (int d = 0; d < 3; ++d) {
-    const int e = d == 0 ? Bx : B, sh = d == 0 ? 0 : S;
-    b.nb[d] = (g.dims[d] + sh + e - 1) / e;
+    const int e = d == 0 ? Bx : B;
+    b.nb[d] = (g.dims[d] + e - 1) / e;
     n *= (uint64_t)b.nb[d];
   }
   b.nbricks = (uint32_t)n;
@@ -227,7 +225,7 @@ __global__ void k_brick_keys(const float4* __restrict__ qf4, uint64_t Q, GridPar
     const int cy = cell_coord_raw(q.y, g.origin[1], g.inv_h, g.dims[1]);
     const int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
     const bool in = cx >= 0 && cx < g.dims[0] && cy >= 0 && cy < g.dims[1] && cz >= 0 && cz < g.dims[2];
-    bid = in ? (uint32_t)(((uint64_t)((cz + b.S) / b.B) * b.nb[1] + ((cy + b.S) / b.B)) * b.nb[0] + (cx / b.Bx)) : b.nbricks;
+    bid = in ? (uint32_t)(((uint64_t)(cz / b.B) * b.nb[1] + (cy / b.B)) * b.nb[0] + (cx / b.Bx)) : b.nbricks;
   }
   keys[i] = bid;
   vals[i] = (uint32_t)i;
@@ -409,8 +407,8 @@ __global__ void k_brick_occupied(GridParams g, BrickParams b, const uint32_t* __
   const int bx = (int)(bid % (uint32_t)b.nb[0]), by = (int)((bid / (uint32_t)b.nb[0]) % (uint32_t)b.nb[1]),
             bz = (int)(bid / ((uint32_t)b.nb[0] * (uint32_t)b.nb[1]));
   const int x0 = max(bx * b.Bx - b.R, 0), x1 = min(bx * b.Bx + b.Bx + b.R, g.dims[0]);
-  const int y0 = max(by * b.B - b.S - b.R, 0), y1 = min(by * b.B - b.S + b.B + b.R, g.dims[1]);
-  const int z0 = max(bz * b.B - b.S - b.R, 0), z1 = min(bz * b.B - b.S + b.B + b.R, g.dims[2]);
+  const int y0 = max(by * b.B - b.R, 0), y1 = min(by * b.B + b.B + b.R, g.dims[1]);
+  const int z0 = max(bz * b.B - b.R, 0), z1 = min(bz * b.B + b.B + b.R, g.dims[2]);
   uint32_t any = 0;
   if (x0 < x1 && y0 < y1 && z0 < z1)
     for (int zq = z0 >> 1; zq < (z1 + 1) >> 1; ++zq)
@@ -474,7 +472,7 @@ __global__ __launch_bounds__(1024) void k_bk_slots(const float4* __restrict__ qf
           const bool in = cx >= 0 && cx < g.dims[0] && cy >= 0 && cy < g.dims[1] && cz >= 0 && cz < g.dims[2];
           s = kSlotFallback;
           if (in) {
-            const uint32_t bid = (uint32_t)(((uint64_t)((cz + b.S) / b.B) * b.nb[1] + ((cy + b.S) / b.B)) * b.nb[0] + (cx / b.Bx));
+            const uint32_t bid = (uint32_t)(((uint64_t)(cz / b.B) * b.nb[1] + (cy / b.B)) * b.nb[0] + (cx / b.Bx));
             if ((brick_slot[bid >> 5] >> (bid & 31u)) & 1u) { s = bid; atomicAdd(&s_h[bid >> shift], 1u); }
           }
         }
@@ -617,8 +615,8 @@ __global__ __launch_bounds__(256) void k_bk_emit(const float4* __restrict__ qf4,
       const int cz = cell_coord_raw(q.z, g.origin[2], g.inv_h, g.dims[2]);
       const uint32_t left = s_off[f + 1] - s_off[f] - r;
       items[ibase + s_ioff[f] + r / (uint32_t)G] =
-          make_uint4(pos, (uint32_t)(cx / b.Bx), (uint32_t)((cy + b.S) / b.B),
-                     (uint32_t)((cz + b.S) / b.B) | ((left < (uint32_t)G ? left : (uint32_t)G) << 28));
+          make_uint4(pos, (uint32_t)(cx / b.Bx), (uint32_t)(cy / b.B),
+                     (uint32_t)(cz / b.B) | ((left < (uint32_t)G ? left : (uint32_t)G) << 28));
     }
     q.w = __uint_as_float(i);
     qsorted[pos] = q;
@@ -656,7 +654,7 @@ __device__ __forceinline__ double proven_bound(const GridParams& g, float qx, fl
 
 }  // namespace pcd
 #include "brick_kernel.h"
-#include "stencil_kernel.h"
+#include "brick_clip_kernel.h"
 namespace pcd {
 
 
@@ -922,64 +920,17 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
 // the hardware's workgroup dispatch as the load balancer (query costs spread 1:4).  2048 / 4096 / 16384 / 65536
 // workgroups: 0.384 / 0.387 / 0.368 / 0.369 ms at workload M, 0.136 / 0.125 / 0.126 / 0.125 ms on an eighth of it.
 constexpr unsigned g_fb_max_blocks = 16384;
-static int g_brick_B = 2, g_brick_R = 2, g_brick_S = 0, g_collect_stats = 0, g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
-// first stage of the grid path: 0 = brick kernel (brick_kernel.h), 1 = per-query stencil stages (stencil_kernel.h).
-// The stencil stages halve the point-query pairs (590 instead of 1 306 per query on workload M) but load every
-// point once PER QUERY instead of once per brick: 9.4 GB through the vector L1s per batch against the brick kernel's
-// 4.4 GB of LDS-DMA, and at 21 TB/s of L1 traffic they take 0.83 ms where the brick kernel takes 0.56
-// (profiles/r03_stencil_probe.txt).  Kept as a tested option (tests/test_nn_gpu.py::test_stencil_stage_cascades).
+static int g_brick_B = 2, g_brick_R = 2, g_collect_stats = 0, g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
+// first stage of the grid path: 0 = the clipped brick kernel (brick_clip_kernel.h; needs the default brick geometry
+// B = R = 2), 1 = the same kernel with the clip switched off (A/B timing: it then stages the whole region like
+// round 3's kernel), 2 = round 3's brick kernel (brick_kernel.h; also what other brick geometries run on).
 static int g_nn_kernel = 0;
-static int g_st_k[3] = {1, 2, 0};            // cube half-widths of the stencil stages in cells (ascending; 0 = unused)
-constexpr unsigned kStencilBlocks = 256 * (16 / kStWaves);  // persistent grid: 16 wavefronts per CU (4 per SIMD) on 256 CUs
-
-template <int KPREV, int K, int BRICK = 0>
-static void launch_stencil(pcd_cloud* c, QueryScratch* sc, const uint32_t* list, const uint32_t* count_ptr,
-                           uint64_t* d_keys, const StencilOut& out, hipStream_t s, const BrickParams& b = BrickParams{}) {
-  hipLaunchKernelGGL((k_nn_stencil<KPREV, K, BRICK>), dim3(kStencilBlocks), dim3(64 * kStWaves), 0, s, c->grid, b, c->sorted.p,
-                     c->cell_start.p, sc->qsorted.p, sc->ksorted.p, list, count_ptr, d_keys, out, sc->counters.p,
-                     g_collect_stats);
-}
-
-// The stencil stages over the brick-sorted queries (positions 0 .. n_in_grid-1); what the last stage cannot prove
-// lands on the fallback list.
-static pcd_status run_stencil_stages(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t* d_keys, hipStream_t s) {
-  int nst = 0;
-  while (nst < 3 && g_st_k[nst] > 0) ++nst;
-  const size_t cap = Q + Q / 8 + 64 + (size_t)kStencilBlocks * kStWaves * 64;
-  if (nst > 1) PCD_TRY(sc->st_list[0].reserve(cap));
-  if (nst > 2) PCD_TRY(sc->st_list[1].reserve(cap));
-  NnCounters* ctr = sc->counters.p;
-  int kprev = 0;
-  for (int i = 0; i < nst; ++i) {
-    const int k = g_st_k[i];
-    const bool last = i + 1 == nst;
-    const uint32_t* list = i == 0 ? nullptr : sc->st_list[(i - 1) & 1].p;
-    const uint32_t* count_ptr = i == 0 ? &ctr->n_in_grid : &ctr->st_count[i - 1];
-    StencilOut out;
-    out.fb_list = sc->fb_list.p; out.fb_count = &ctr->fb_count;
-    out.next_list = last ? sc->fb_list.p : sc->st_list[i & 1].p;
-    out.next_count = last ? &ctr->fb_count : &ctr->st_count[i];
-    out.next_is_fallback = last ? 1 : 0;
-    const int combo = kprev * 4 + k;
-    switch (combo) {
-      case 0 * 4 + 1: launch_stencil<0, 1>(c, sc, list, count_ptr, d_keys, out, s); break;
-      case 0 * 4 + 2: launch_stencil<0, 2>(c, sc, list, count_ptr, d_keys, out, s); break;
-      case 0 * 4 + 3: launch_stencil<0, 3>(c, sc, list, count_ptr, d_keys, out, s); break;
-      case 1 * 4 + 2: launch_stencil<1, 2>(c, sc, list, count_ptr, d_keys, out, s); break;
-      case 1 * 4 + 3: launch_stencil<1, 3>(c, sc, list, count_ptr, d_keys, out, s); break;
-      case 2 * 4 + 3: launch_stencil<2, 3>(c, sc, list, count_ptr, d_keys, out, s); break;
-      default: set_error("stencil stages must ascend within 1..3 (got %d after %d)", k, kprev); return PCD_ERR_INVALID;
-    }
-    kprev = k;
-  }
-  return PCD_OK;
-}
 
 static int g_bk_sort = 0;   // 1: force the radix-sort bookkeeping (A/B timing, tests)
 
 // slot table of the cloud for this brick geometry (built on first use, rebuilt when the geometry changes)
 static pcd_status brick_slots(pcd_cloud* c, QueryScratch* sc, const BrickParams& b, hipStream_t s) {
-  const int key[5] = {b.B, b.R, b.S, b.Bx, (int)b.nbricks};
+  const int key[5] = {b.B, b.R, 0, b.Bx, (int)b.nbricks};
   if (sc->bk_slot.p && std::memcmp(key, sc->bk_slot_key, sizeof key) == 0) return PCD_OK;
   PCD_TRY(sc->bk_slot.reserve((size_t)b.nbricks / 32 + 1));
   DevBuf<uint32_t> flag;
@@ -999,13 +950,13 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   if ((B + 2 * R) * (B + 2 * R) > kMaxRows) { B = 2; R = 2; }
   // x-long bricks (Bx = 2B, 3B, 4B: fewer, fuller groups but a longer region per query) were measured on workload M:
   // 0.638 / 0.698 / 0.768 ms against 0.633 ms for cubes (profiles/r02_nn_config_sweeps.txt)
-  const BrickParams b = make_bricks(g, B, B, R, g_brick_S);
+  const BrickParams b = make_bricks(g, B, B, R);
   PCD_TRY(sc->qsorted.reserve(Q));
   PCD_TRY(sc->ksorted.reserve(Q));
   // fallback list: one slot per query + the chunk slack of every wavefront of the brick kernel (brick_kernel.h)
   // A wavefront leaves a chunk when the next item's unproven queries (<= 8) do not fit: at most 7 of 64 slots stay
   // unused per chunk, so the reserved slots are <= used * 64 / 57 + one chunk per wavefront, used <= Q.
-  const size_t fb_cap = Q + Q / 8 + 8 + (size_t)std::max<unsigned>(256 * g_brick_blocks_per_cu * 4, kStencilBlocks * kStWaves) * kFbChunk +
+  const size_t fb_cap = Q + Q / 8 + 8 + (size_t)256 * g_brick_blocks_per_cu * 4 * kFbChunk +
                         (size_t)2048 * 4 * 64;   // + the last chunk of every wavefront of k_bk_emit
   PCD_TRY(sc->fb_list.reserve(fb_cap));   // no memset: every reserved slot is written (a query id or the sentinel)
   PCD_TRY(sc->bk_keys.reserve(2 * Q));
@@ -1060,31 +1011,18 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
                        refine ? d_keys : (const uint64_t*)nullptr, (uint32_t)Q, b.nbricks, (uint32_t)b.nb[0],
                        (uint32_t)b.nb[1], sc->items.p, sc->qsorted.p, sc->ksorted.p, sc->fb_list.p, sc->counters.p);
   }
-  // (the stencil kernel addresses `sorted` with 32-bit byte offsets: clouds of 2^28 records and more take the brick kernel)
-  if (g_nn_kernel == 1 && c->m + kSortedSpare < (1ull << 28)) {
-    ScopedKernelTimer t("nn_stencil", s);
-    PCD_TRY(run_stencil_stages(c, sc, Q, d_keys, s));
-  } else {
-    // g_nn_kernel == 2: the brick kernel with a small region, then ONE ball-clipped stencil stage over the +-3 cube of
-    // every query the brick kernel could not prove (stencil_kernel.h, BRICK = 1)
-    const bool second = g_nn_kernel == 2 && c->m + kSortedSpare < (1ull << 28);
-    const size_t cap = Q + Q / 8 + 64 + (size_t)256 * g_brick_blocks_per_cu * 4 * kFbChunk;
-    if (second) PCD_TRY(sc->st_list[0].reserve(cap));
-    {
-      ScopedKernelTimer t("nn_brick", s);
-      const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(div_up(Q, G), 4) + 1, 256 * (uint64_t)g_brick_blocks_per_cu);
+  {
+    ScopedKernelTimer t("nn_brick", s);
+    const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(div_up(Q, G), 4) + 1, 256 * (uint64_t)g_brick_blocks_per_cu);
+    if (g_nn_kernel != 2 && B == 2 && R == 2) {
+      const ClipConst cc{{(double)g.origin[0], (double)g.origin[1], (double)g.origin[2]}, (double)g.h, (double)g.slack};
+      hipLaunchKernelGGL(k_nn_brick_clip, dim3(blocks), dim3(256), 0, s, g, cc, c->sorted.p, c->cell_start.p, sc->qsorted.p,
+                         sc->ksorted.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p, &sc->counters.p->fb_count,
+                         (g_collect_stats & ~2) | (g_nn_kernel == 1 ? 2 : 0));
+    } else
       hipLaunchKernelGGL(k_nn_brick<G>, dim3(blocks), dim3(256), 0, s, g, b, c->sorted.p, c->cell_start.p,
-                         sc->qsorted.p, sc->ksorted.p, sc->items.p, sc->counters.p, d_keys,
-                         second ? sc->st_list[0].p : sc->fb_list.p,
-                         second ? &sc->counters.p->st_count[0] : &sc->counters.p->fb_count, g_collect_stats | (second ? 2 : 0));
-    }
-    if (second) {
-      ScopedKernelTimer t("nn_ball", s);
-      StencilOut out;
-      out.fb_list = sc->fb_list.p; out.fb_count = &sc->counters.p->fb_count;
-      out.next_list = sc->fb_list.p; out.next_count = &sc->counters.p->fb_count; out.next_is_fallback = 1;
-      launch_stencil<0, 3, 1>(c, sc, sc->st_list[0].p, &sc->counters.p->st_count[0], d_keys, out, s, b);
-    }
+                         sc->qsorted.p, sc->ksorted.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p,
+                         &sc->counters.p->fb_count, g_collect_stats);
   }
   {
     ScopedKernelTimer t("nn_fallback", s);
@@ -1261,35 +1199,16 @@ pcd_status pcd_nn_last_stats(pcd_cloud* c, pcd_nn_stats* st) {
   return PCD_OK;
 }
 
-/* tuning hook: which kernel serves the grid path's first stage (1 = stencil stages of half-widths k1 < k2 < k3 cells,
- * 0 = unused stage; 0 = brick kernel).  Negative kernel: leave everything as it is. */
-pcd_status pcd_nn_set_search(int kernel, int k1, int k2, int k3) {
+/* tuning hook: which kernel serves the grid path's first stage (g_nn_kernel above).  Negative: leave it as it is. */
+pcd_status pcd_nn_set_search(int kernel) {
   if (kernel < 0) return PCD_OK;
-  PCD_REQUIRE(kernel >= 0 && kernel <= 2, "kernel must be 0 (brick), 1 (stencil) or 2 (brick + ball-clipped stencil stage)");
-  if (kernel == 1) {
-    const int k[3] = {k1, k2, k3};
-    int prev = 0;
-    bool ended = false;
-    for (int i = 0; i < 3; ++i) {
-      if (k[i] <= 0) { ended = true; continue; }
-      PCD_REQUIRE(!ended && k[i] > prev && k[i] <= 3, "stencil half-widths must ascend within 1..3");
-      prev = k[i];
-    }
-    PCD_REQUIRE(k1 > 0, "at least one stencil stage");
-    for (int i = 0; i < 3; ++i) g_st_k[i] = k[i] > 0 ? k[i] : 0;
-  }
+  PCD_REQUIRE(kernel <= 2, "kernel must be 0 (clipped brick kernel), 1 (the same, clip off) or 2 (round 3's brick kernel)");
   g_nn_kernel = kernel;
   return PCD_OK;
 }
 
 pcd_status pcd_nn_set_bookkeeping(int radix_sort) {
   g_bk_sort = radix_sort ? 1 : 0;
-  return PCD_OK;
-}
-
-pcd_status pcd_nn_set_brick_shift(int shift) {
-  PCD_REQUIRE(shift == 0 || shift == 1, "shift must be 0 or 1");
-  g_brick_S = shift;
   return PCD_OK;
 }
 

@@ -9,7 +9,7 @@ struct NnCounters {
   unsigned int nitems, fb_count;
   unsigned int pad[2];   // pad[0] = length of the squeezed fallback list
   unsigned int n_in_grid;     // brick-sorted positions 0 .. n_in_grid-1 are the finite queries inside the grid
-  unsigned int st_count[3];   // slots handed out in the stencil stages' output lists (stencil_kernel.h)
+  unsigned int pad2[3];
   unsigned int fb_max_steps, fb_max_leaves;   // statistics passes: longest walk of k_nn_fallback (steps, leaf scans)
   unsigned long long fb_steps, fb_leaves;
 };
@@ -22,14 +22,12 @@ struct QueryScratch {
   // counting-sort bookkeeping (nn.hip): slot of every brick with a non-empty halo region (kSlotNone otherwise), valid
   // for the brick geometry in bk_slot_key; per batch the slots' query counters, in-tile prefixes and tile totals
   DevBuf<uint32_t> bk_slot, bk_chist;   // bk_chist: coarse histogram | bucket starts | bucket cursors
-  DevBuf<uint4> bk_state;               // BkState (nn.hip)
   int bk_slot_key[5] = {0, 0, 0, 0, 0};
   uint32_t bk_nslots = 0;
   DevBuf<float4> qsorted;      // brick-sorted query records {x,y,z,bits(query id)}
   DevBuf<uint64_t> ksorted;    // their incoming keys, same order
   DevBuf<uint4> items;         // {first query, brick x, brick y, brick z | count << 28}
   DevBuf<uint32_t> fb_list, fb_dense;   // fallback list as the brick kernel fills it (chunked) / squeezed
-  DevBuf<uint32_t> st_list[2];          // stencil stages' lists of unproven queries (sorted positions, chunked)
   DevBuf<NnCounters> counters;
   DevBuf<char> tmp;
   DevBuf<double> d_q;          // staging of host queries

@@ -601,17 +601,13 @@ def set_nn_tuning(brick_cells=0, halo_cells=-1, collect_stats=0):
     lib().pcd_nn_set_tuning(int(brick_cells), int(halo_cells), int(collect_stats))
 
 
-def set_nn_search(kernel=1, k1=1, k2=2, k3=0):
-    """first stage of the grid path: kernel 1 = stencil stages of half-widths k1 < k2 < k3 cells (0 = unused), 0 = brick kernel"""
-    _check(lib().pcd_nn_set_search(int(kernel), int(k1), int(k2), int(k3)))
+def set_nn_search(kernel=0):
+    """first stage of the grid path: 0 = clipped brick kernel (default), 1 = the same with the clip off, 2 = round 3's kernel"""
+    _check(lib().pcd_nn_set_search(int(kernel)))
 
 
 def set_nn_bookkeeping(radix_sort=0):
     _check(lib().pcd_nn_set_bookkeeping(int(radix_sort)))
-
-
-def set_brick_shift(shift=0):
-    _check(lib().pcd_nn_set_brick_shift(int(shift)))
 
 
 def profile_enable(on=True):

@@ -328,12 +328,7 @@ def test_config_A_one_launch_path(gpu, oracle):
     c.close()
 
 
-@pytest.mark.parametrize("stages", [(1, 0, 0), (1, 2, 0), (1, 2, 3), (1, 3, 0), (2, 3, 0), (3, 0, 0)])
-def test_stencil_stage_cascades(gpu, oracle, stages):
-    """The per-query stencil stages (csrc/stencil_kernel.h) as first stage of the grid path: every cascade of cube
-    half-widths must give the oracle's keys bit for bit -- on a surface cloud, on exact ties (duplicates, the lattice)
-    and on a cloud with cells far denser than a stage's step table (those queries take the overflow route to the
-    pyramid search)."""
+def _hard_cases():
     rng = np.random.default_rng(31)
     cases = dict(_clouds())
     dense, dn = synth.cloud_uniform(30000, seed=5, box=np.array([6.0, 6.0, 6.0]))
@@ -341,48 +336,64 @@ def test_stencil_stage_cascades(gpu, oracle, stages):
     cases["dense_cell"] = (dense, dn)
     lat = np.stack(np.meshgrid(np.arange(40), np.arange(30), np.arange(20), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.25
     cases["lattice"] = (lat, np.ones_like(lat))
-    try:
-        gpu.set_nn_search(1, *stages)
-        for name, (xyz, nrm) in cases.items():
-            q = synth.queries(xyz, 6000, seed=7)
-            q[:300] = xyz[rng.integers(0, xyz.shape[0], 300)].astype(np.float64)
-            if name == "lattice":
-                q[300:900] = np.round(q[300:900] / 0.125) * 0.125      # midway between lattice points: exact ties
-            c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
-            _check_exact(c.nn(q, gpu.NN_GRID), oracle.nn_bruteforce(xyz, q), f"stencil{stages}/{name}")
-            c.close()
-    finally:
-        gpu.set_nn_search(0)
+    # a thin sheet: every brick holds a few points, the balls of most queries reach into the halo rows
+    sheet = (rng.random((40000, 3)) * np.array([30.0, 30.0, 0.02])).astype(np.float32)
+    cases["sheet"] = (sheet, np.tile(np.array([0, 0, 1], np.float32), (40000, 1)))
+    return cases
 
 
-@pytest.mark.parametrize("brs", [(2, 1, 1), (2, 2, 0), (2, 1, 0), (4, 1, 1)])
-def test_brick_then_ball_clipped_stage(gpu, oracle, brs):
-    """Grid path as brick kernel with a small halo region + one ball-clipped stencil stage over the +-3 cube
-    (pcd_nn_set_search(2)): bit-equal to the oracle for shifted and unshifted bricks, incl. ties and dense cells."""
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_brick_kernel_variants(gpu, oracle, kernel):
+    """First stage of the grid path: 0 = the clipped brick kernel (csrc/brick_clip_kernel.h: the brick's own cells first,
+    then only the quad-row parts the queries' balls touch), 1 = the same kernel with the clip switched off, 2 = round
+    3's whole-region kernel.  All three must give the oracle's keys bit for bit -- on a surface cloud, on exact ties
+    (duplicates, lattice midpoints), on a cell far denser than stage A's 128 points, on a thin sheet, with near and far
+    queries, on several cell sizes (regions that leave the grid on every side)."""
     rng = np.random.default_rng(32)
-    cases = dict(_clouds())
-    dense, dn = synth.cloud_uniform(30000, seed=5, box=np.array([6.0, 6.0, 6.0]))
-    dense[:12000] = dense[0] + rng.normal(0, 2e-3, (12000, 3)).astype(np.float32)
-    cases["dense_cell"] = (dense, dn)
-    lat = np.stack(np.meshgrid(np.arange(40), np.arange(30), np.arange(20), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.25
-    cases["lattice"] = (lat, np.ones_like(lat))
     try:
-        gpu.set_nn_search(2)
-        gpu.set_nn_tuning(brs[0], brs[1], 0)
-        gpu.set_brick_shift(brs[2])
-        for name, (xyz, nrm) in cases.items():
-            for sigma in (0.25, 1.0):
+        gpu.set_nn_search(kernel)
+        for name, (xyz, nrm) in _hard_cases().items():
+            for sigma, cell in ((0.02, 0.0), (0.25, 0.0), (1.0, 0.0), (0.1, 0.6)):
                 q = synth.queries(xyz, 6000, seed=7, sigma=sigma)
                 q[:300] = xyz[rng.integers(0, xyz.shape[0], 300)].astype(np.float64)
                 if name == "lattice":
-                    q[300:900] = np.round(q[300:900] / 0.125) * 0.125
-                c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
-                _check_exact(c.nn(q, gpu.NN_GRID), oracle.nn_bruteforce(xyz, q), f"brick+ball{brs}/{name}/sigma{sigma}")
+                    q[300:900] = np.round(q[300:900] / 0.125) * 0.125      # midway between lattice points: exact ties
+                c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False, cell_size=cell)
+                _check_exact(c.nn(q, gpu.NN_GRID), oracle.nn_bruteforce(xyz, q), f"kernel{kernel}/{name}/sigma{sigma}/cell{cell}")
                 c.close()
     finally:
         gpu.set_nn_search(0)
+
+
+@pytest.mark.parametrize("br", [(2, 1), (4, 1), (3, 2)])
+def test_other_brick_geometries(gpu, oracle, br):
+    """brick edges / halos other than the default 2 / 2 run on round 3's kernel (pcd_nn_set_tuning): still exact"""
+    xyz, nrm = _clouds()["planes"]
+    q = synth.queries(xyz, 6000, seed=9, sigma=0.3)
+    try:
+        gpu.set_nn_tuning(br[0], br[1], 0)
+        c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+        _check_exact(c.nn(q, gpu.NN_GRID), oracle.nn_bruteforce(xyz, q), f"brick{br}")
+        c.close()
+    finally:
         gpu.set_nn_tuning(2, 2, 0)
-        gpu.set_brick_shift(0)
+
+
+def test_clip_with_incoming_bounds(gpu, oracle):
+    """the clip radius comes from the key a query arrives with when stage A finds nothing nearer: gate-bounded
+    association (bound = gate) on the clipped kernel must accept exactly what the unbounded search + gate accept"""
+    xyz, nrm = synth.cloud_planes(60000, seed=11, patches=12)
+    q = synth.queries(xyz, 90000, seed=12, sigma=0.15)     # > 65536: the grid path
+    c = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    mr = np.full(q.shape[0], 0.2)
+    a = c.associate(q, mr, gpu.GATE_MAPPER_LOCAL)
+    b = c.associate(q, mr, gpu.GATE_MAPPER_LOCAL | gpu.GATE_BOUNDED_SEARCH)
+    assert np.array_equal(a["type"], b["type"])
+    acc = a["type"] != 0
+    assert acc.any() and (~acc).any()
+    assert np.array_equal(a["nn_idx"][acc], b["nn_idx"][acc])
+    assert np.array_equal(a["abcd"][acc].view(np.uint64), b["abcd"][acc].view(np.uint64))
+    c.close()
 
 
 def test_radix_sort_bookkeeping_still_exact(gpu, oracle):

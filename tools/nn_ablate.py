@@ -17,11 +17,16 @@ c = pcdhip.Cloud(xyz, nrm, raw_lidar_frame=False)
 dq = torch.from_numpy(q).cuda()
 keys = torch.empty(Q, dtype=torch.int64, device="cuda")
 F = 0x800  # never hand anything to the fallback (keeps the brick kernel's control flow comparable)
-for name, fl in [("full", 0), ("full, no fallback list", F), ("no-compare", F | 0x100), ("quarter compare", F | 0x2000),
-                 ("no-reduce", F | 0x400), ("no DMA (stale LDS)", F | 0x4000), ("no DMA, no LDS read", F | 0xC000),
-                 ("no DMA, no LDS read, no compare", F | 0xC100), ("no LDS read", F | 0x8000),
-                 ("no-compare+no-reduce", F | 0x500), ("no tile loop, no reduce", F | 0x1400), ("no tile loop", F | 0x1000),
-                 ("full", 0)]:
+# k_nn_brick_clip (csrc/brick_clip_kernel.h): 0x100 no compare, 0x400 no reductions, 0x1000 no stage B, 0x10000 no clip
+# arithmetic (whole region), 0x20000 no region bound, 0x40000 no stage A
+for name, fl in [("full", 0), ("full, no fallback list", F), ("no compare", F | 0x100), ("no reductions", F | 0x400),
+                 ("no stage B", F | 0x1000), ("no stage A", F | 0x40000), ("no region bound", F | 0x20000),
+                 ("no clip arithmetic (whole region)", F | 0x10000), ("no stage B, no stage A", F | 0x41000),
+                 ("no stage B / A / reductions / bound", F | 0x61400),
+                 ("no compare, no reductions, no bound", F | 0x20500),
+                 ("no DMA (stale LDS)", F | 0x4000), ("no LDS read", F | 0x8000), ("no DMA, no LDS read", F | 0xC000),
+                 ("no range select", F | 0x80000), ("no DMA, no LDS read, no select", F | 0x8C000),
+                 ("no DMA, no LDS read, no select, no compare", F | 0x8C100), ("full", 0)]:
     pcdhip.set_nn_tuning(0, -1, fl)
     for _ in range(3):
         c.nn_device(dq, Q, keys)
