@@ -15,6 +15,7 @@
 #include "ba_problem.h"
 #include "ceres_adapter.h"
 #include "pose_reader.h"
+#include "pose_writer.h"
 #include "sift_match_hip.h"
 #include "exhaustive_matcher_hip.h"
 #include "lidar_hip.h"
@@ -328,6 +329,86 @@ static void TestPoseReader() {
   CHECK(std::fabs(poses[4][2] - 5.0) < 1e-12 && std::fabs(poses[4][0]) < 1e-12);
   std::remove(path.c_str());
   CHECK(!LoadPosePly("/tmp/pcdhip_no_such_pose.ply", &poses));
+}
+
+// SaveImagePoses (ui/main_window.cc:1078-1182): hand-computed poses, the "nan" rows, and the round trip through LoadPose
+static void TestPoseWriter() {
+  const std::string path = "/tmp/pcdhip_pose_writer_test.ply";
+  const double h = std::sqrt(0.5), kPi = 3.14159265358979323846;
+  std::map<uint32_t, std::array<double, 7>> poses;
+  poses[1] = {2, 3, -1, 1, 0, 0, 0};        // R = I, t_cw = (2, 3, -1): camera at t_wc = (-2, -3, 1) = LiDAR (1, 2, 3)
+  poses[3] = {0, 0, 0, h, 0, h, 0};         // q_cw = rotation by +90 deg about y: the camera looks along LiDAR +y, yaw = +pi/2
+  poses[4] = {0, 0, 5, 0, 0, 1, 0};         // half turn about the vertical axis, camera at LiDAR x = 5 (pose_reader test, image 4)
+  poses[6] = {0, 0, 0, std::cos(0.25), 0, 0, std::sin(0.25)};   // R_cw = Rz(0.5): R_wc = Rz(-0.5), roll = -0.5
+  poses[7] = {0, 0, 0, std::cos(0.2), std::sin(0.2), 0, 0};     // R_cw = Rx(0.4): R_wc = Rx(-0.4), Euler x angle -0.4, pitch = +0.4
+  CHECK(SaveImagePosesPly(path, 8, poses));
+  std::vector<std::string> lines;
+  {
+    std::ifstream f(path);
+    std::string l;
+    while (std::getline(f, l)) lines.push_back(l);
+  }
+  CHECK_EQ(lines.size(), 10u + 8u);
+  CHECK(lines[0] == "ply" && lines[1] == "format ascii 1.0" && lines[2] == "element vertex 8");
+  CHECK(lines[3] == "property float x" && lines[6] == "property float roll" && lines[7] == "property float pitch" &&
+        lines[8] == "property float yaw" && lines[9] == "end_header");
+  CHECK(lines[10 + 1] == "nan nan nan nan nan nan" && lines[10 + 4] == "nan nan nan nan nan nan" &&
+        lines[10 + 7] == "nan nan nan nan nan nan");
+  auto parse = [&](int id) {
+    std::array<double, 6> v{};
+    std::stringstream ss(lines[10 + id - 1]);
+    for (double& x : v) ss >> x;
+    return v;
+  };
+  auto near6 = [&](int id, std::array<double, 6> e) {
+    const auto v = parse(id);
+    bool ok = true;
+    for (int k = 0; k < 6; ++k) ok = ok && std::fabs(v[k] - e[k]) < 1e-5 * std::max(1.0, std::fabs(e[k]));   // 6 significant digits in the file
+    return ok;
+  };
+  CHECK(near6(1, {1, 2, 3, 0, 0, 0}));
+  CHECK(near6(3, {0, 0, 0, 0, 0, kPi / 2}));          // through the fold: eulerAngles gives (pi/2, -pi, +-pi)
+  {
+    const auto v = parse(4);                          // a half turn: yaw = +-pi, the camera at x = 5
+    CHECK(std::fabs(v[0] - 5) < 1e-5 && std::fabs(v[1]) < 1e-5 && std::fabs(v[2]) < 1e-5);
+    CHECK(std::fabs(std::fabs(v[5]) - kPi) < 1e-5 && std::fabs(v[3]) < 1e-5 && std::fabs(v[4]) < 1e-5);
+  }
+  CHECK(near6(6, {0, 0, 0, -0.5, 0, 0}));
+  CHECK(near6(7, {0, 0, 0, 0, 0.4, 0}));
+  // the reader gives the poses back (float text: 6 significant digits)
+  std::map<uint32_t, std::array<double, 7>> back;
+  CHECK(LoadPosePly(path, &back));
+  CHECK_EQ(back.size(), poses.size());
+  for (const auto& kv : poses) {
+    CHECK(back.count(kv.first));
+    const auto& a = kv.second;
+    const auto& b = back[kv.first];
+    const double sgn = (a[3] * b[3] + a[4] * b[4] + a[5] * b[5] + a[6] * b[6]) < 0 ? -1.0 : 1.0;   // q and -q are one rotation
+    for (int k = 0; k < 3; ++k) CHECK(std::fabs(a[k] - b[k]) < 2e-5);
+    for (int k = 3; k < 7; ++k) CHECK(std::fabs(a[k] - sgn * b[k]) < 2e-5);
+  }
+  // round trip from the LiDAR side over a grid of angles (|pitch| < pi/2, angles away from +-pi where the sign is free)
+  std::map<uint32_t, std::array<double, 7>> grid;
+  std::vector<std::array<double, 6>> src;
+  uint32_t id = 0;
+  for (double roll : {-2.9, -1.0, 0.0, 0.7, 3.0})
+    for (double pitch : {-1.5, -0.6, 0.0, 0.3, 1.4})
+      for (double yaw : {-3.0, -1.8, -0.2, 0.0, 0.9, 2.6}) {
+        const std::array<double, 6> p = {1.5 + id, -2.0 + 0.25 * id, 0.125 * id, roll, pitch, yaw};
+        src.push_back(p);
+        grid[++id] = LidarPoseToColmap(p.data());
+      }
+  CHECK(SaveImagePosesPly(path, (int)id, grid));
+  lines.clear();
+  {
+    std::ifstream f(path);
+    std::string l;
+    while (std::getline(f, l)) lines.push_back(l);
+  }
+  CHECK_EQ(lines.size(), 10u + id);
+  for (uint32_t i = 1; i <= id; ++i) CHECK(near6((int)i, src[i - 1]));
+  std::remove(path.c_str());
+  CHECK(!SaveImagePosesPly("/tmp/pcdhip_no_such_dir/pose.ply", 1, poses));
 }
 
 static void TestPlyReader() {
@@ -866,6 +947,7 @@ int main(int argc, char** argv) {
   TestLidarBlocks();
   TestPlyReader();
   TestPoseReader();
+  TestPoseWriter();
   TestMatchVariablePoint();
   TestCeresBlockShapes();
   TestExhaustiveBlocks();
