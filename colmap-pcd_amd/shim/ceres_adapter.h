@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <unordered_map>
 #include <vector>
 
 #if __has_include(<ceres/ceres.h>)
@@ -60,6 +61,7 @@ struct ShimParameterSource {
 struct HipBlockBuffers {   // results of the last PrepareForEvaluation, read by every block: views of the pinned host
   pcd_ba_blocks b{};       // buffers the pcd_ba handle owns (pcd_ba_evaluate_blocks)
   bool have_jacobians = false;
+  size_t num_obs = 0;      // reprojection blocks of the problem: the lidar residuals follow their 2 * num_obs entries
 };
 
 // one reprojection residual block (variable or constant pose), optim/bundle_adjustment.cc:858-893, :967-983
@@ -106,12 +108,12 @@ class HipReprojectionBlock : public ceres::CostFunction {
 // one point-to-plane residual block, optim/bundle_adjustment.cc:1031-1037
 class HipLidarBlock : public ceres::CostFunction {
  public:
-  HipLidarBlock(const HipBlockBuffers* buf, size_t num_obs, size_t l) : buf_(buf), O_(num_obs), l_(l) {
+  HipLidarBlock(const HipBlockBuffers* buf, size_t l) : buf_(buf), l_(l) {
     set_num_residuals(1);
     mutable_parameter_block_sizes()->push_back(3);
   }
   bool Evaluate(double const* const*, double* residuals, double** jacobians) const override {
-    residuals[0] = buf_->b.residuals[2 * O_ + l_];
+    residuals[0] = buf_->b.residuals[2 * buf_->num_obs + l_];
     if (jacobians && jacobians[0]) {
       if (!buf_->have_jacobians) return false;
       std::memcpy(jacobians[0], buf_->b.jac_lidar + 3 * l_, 3 * sizeof(double));
@@ -121,7 +123,7 @@ class HipLidarBlock : public ceres::CostFunction {
 
  private:
   const HipBlockBuffers* buf_;
-  size_t O_, l_;
+  size_t l_;
 };
 
 template <typename Source = ShimParameterSource>
@@ -130,6 +132,7 @@ class HipEvaluation : public ceres::EvaluationCallback {
   // `ba` must have been SetUp() and Create()d; `src` gives the parameter memory Ceres optimises in place
   HipEvaluation(BundleAdjusterHip* ba, const Source& src) : ba_(ba), src_(src) {
     for (uint8_t v : ba_->cam_refine_) cameras_variable_ |= v != 0;
+    buf_.num_obs = ba_->obs_image_.size();
   }
 
   void PrepareForEvaluation(bool evaluate_jacobians, bool new_evaluation_point) override {
@@ -165,7 +168,7 @@ class HipEvaluation : public ceres::EvaluationCallback {
     return new HipReprojectionBlock(&buf_, o, ba_->image_const_pose_[im] != 0,
                                     pcd_camera_num_params(ba_->cam_model_[ba_->image_cam_[im]]));
   }
-  ceres::CostFunction* LidarBlock(size_t l) const { return new HipLidarBlock(&buf_, ba_->obs_image_.size(), l); }
+  ceres::CostFunction* LidarBlock(size_t l) const { return new HipLidarBlock(&buf_, l); }
 
   bool ok() const { return ok_; }
   size_t num_evaluations() const { return num_evaluations_; }
@@ -179,6 +182,126 @@ class HipEvaluation : public ceres::EvaluationCallback {
   bool cameras_variable_ = false, ok_ = true;
   size_t num_evaluations_ = 0;
   uint64_t bytes_d2h_ = 0;
+};
+
+// The same route WITHOUT a mirror of the scene: the reference's own SetUp* / AddImageToProblem / AddPointToProblem /
+// AddLidarToProblem keep walking colmap::Reconstruction and call AddResidualBlock exactly as they do today; only the
+// cost-function object they create comes from this recorder (integration/colmap-pcd-hip.patch), which notes, in creation
+// order, the addresses of the parameter blocks the block is added with.  Addresses identify images (qvec), points (xyz)
+// and cameras (params) -- they are what Ceres itself keys parameter blocks on.  Finalize() (after SetUp*, before
+// ceres::Solve) builds the flat pcd_ba from those notes; from then on it is HipEvaluation's loop: gather the evaluation
+// point through the addresses, ONE pcd_ba_evaluate_blocks, every block's Evaluate copies.  Which blocks are constant is
+// Ceres' knowledge (SetParameterBlockConstant / manifolds): it passes jacobians[i] == NULL for them.
+class HipBlockRecorder : public ceres::EvaluationCallback {
+ public:
+  ~HipBlockRecorder() override { pcd_ba_destroy(ba_); }
+
+  // optim/bundle_adjustment.cc:858-893 / :967-983.  constant_pose: the block is added WITHOUT qvec / tvec (the
+  // reference's BundleAdjustmentConstantPoseCostFunction copies the pose at creation; here it is read at Finalize()).
+  ceres::CostFunction* AddReprojection(int camera_model_id, double* qvec, double* tvec, double* xyz, double* params,
+                                       const double* xy, bool constant_pose) {
+    const int cam = Index(&cam_index_, params, &cam_ptr_);
+    if (cam == (int)cam_model_.size()) {
+      cam_model_.push_back(camera_model_id);
+      cam_off_.push_back((int32_t)cam_len_);
+      cam_len_ += (size_t)pcd_camera_num_params(camera_model_id);
+    }
+    const int im = Index(&image_index_, qvec, &qvec_ptr_);
+    if (im == (int)image_cam_.size()) {
+      tvec_ptr_.push_back(tvec);
+      image_cam_.push_back(cam);
+      image_const_pose_.push_back(constant_pose ? 1 : 0);
+    }
+    const int pt = Index(&point_index_, xyz, &xyz_ptr_);
+    obs_image_.push_back(im);
+    obs_point_.push_back(pt);
+    obs_xy_.push_back(xy[0]);
+    obs_xy_.push_back(xy[1]);
+    return new HipReprojectionBlock(&buf_, obs_image_.size() - 1, constant_pose, pcd_camera_num_params(camera_model_id));
+  }
+  // optim/bundle_adjustment.cc:1031-1037
+  ceres::CostFunction* AddLidar(double* xyz, const double* abcd, double weight) {
+    lidar_point_.push_back(Index(&point_index_, xyz, &xyz_ptr_));
+    lidar_abcd_.insert(lidar_abcd_.end(), abcd, abcd + 4);
+    lidar_w_.push_back(weight);
+    return new HipLidarBlock(&buf_, lidar_point_.size() - 1);
+  }
+  size_t NumResiduals() const { return 2 * obs_image_.size() + lidar_point_.size(); }
+
+  // cameras_variable: some camera parameter block is optimised (ParameterizeCameras, :1047-1100): its Jacobians are
+  // computed and copied only then.  Returns false when there is nothing to evaluate or the device refuses.
+  bool Finalize(int device, bool cameras_variable) {
+    if (NumResiduals() == 0) return false;
+    cameras_variable_ = cameras_variable;
+    buf_.num_obs = obs_image_.size();
+    poses_.resize(7 * qvec_ptr_.size());
+    points_.resize(3 * xyz_ptr_.size());
+    cam_params_.resize(cam_len_);
+    Gather(true);
+    std::vector<uint8_t> const_tvec(qvec_ptr_.size(), 0), point_const(xyz_ptr_.size(), 0);
+    std::vector<uint8_t> refine(cam_len_, cameras_variable ? 1 : 0);
+    pcd_ba_desc d{};
+    d.device = device;
+    d.num_cameras = (int32_t)cam_model_.size(); d.cam_model = cam_model_.data(); d.cam_param_offset = cam_off_.data();
+    d.cam_params = cam_params_.data(); d.cam_params_len = cam_params_.size();
+    d.num_images = (int32_t)qvec_ptr_.size(); d.poses = poses_.data(); d.image_camera = image_cam_.data();
+    d.image_const_pose = image_const_pose_.data(); d.image_const_tvec = const_tvec.data();
+    d.num_points = (int32_t)xyz_ptr_.size(); d.points = points_.data(); d.point_const = point_const.data();
+    d.num_obs = obs_image_.size(); d.obs_image = obs_image_.data(); d.obs_point = obs_point_.data(); d.obs_xy = obs_xy_.data();
+    d.num_lidar = lidar_point_.size(); d.lidar_point = lidar_point_.data(); d.lidar_abcd = lidar_abcd_.data();
+    d.lidar_weight = lidar_w_.data();
+    d.loss_type = PCD_LOSS_TRIVIAL; d.loss_scale = 1.0;    // Ceres applies the loss function to the raw blocks itself
+    d.camera_refine = cameras_variable ? refine.data() : nullptr;
+    pcd_ba_destroy(ba_);
+    ba_ = nullptr;
+    return pcd_ba_create(&d, &ba_) == PCD_OK;
+  }
+
+  void PrepareForEvaluation(bool evaluate_jacobians, bool new_evaluation_point) override {
+    ok_ = ba_ != nullptr;
+    if (!ok_) return;
+    if (new_evaluation_point) {
+      Gather(cameras_variable_);
+      ok_ &= pcd_ba_set_parameters(ba_, poses_.data(), points_.data()) == PCD_OK;
+      if (cameras_variable_) ok_ &= pcd_ba_set_camera_parameters(ba_, cam_params_.data()) == PCD_OK;
+    }
+    ok_ &= pcd_ba_evaluate_blocks(ba_, evaluate_jacobians ? 1 : 0, cameras_variable_ ? 1 : 0, &buf_.b) == PCD_OK;
+    buf_.have_jacobians = evaluate_jacobians && ok_;
+    ++num_evaluations_;
+  }
+  bool ok() const { return ok_; }
+  size_t num_evaluations() const { return num_evaluations_; }
+  pcd_ba* handle() const { return ba_; }
+
+ private:
+  static int Index(std::unordered_map<const double*, int>* index, double* ptr, std::vector<double*>* ptrs) {
+    const auto it = index->find(ptr);
+    if (it != index->end()) return it->second;
+    const int idx = (int)ptrs->size();
+    (*index)[ptr] = idx;
+    ptrs->push_back(ptr);
+    return idx;
+  }
+  void Gather(bool cameras) {
+    for (size_t i = 0; i < qvec_ptr_.size(); ++i) {
+      std::memcpy(&poses_[7 * i], qvec_ptr_[i], 4 * sizeof(double));
+      std::memcpy(&poses_[7 * i + 4], tvec_ptr_[i], 3 * sizeof(double));
+    }
+    for (size_t p = 0; p < xyz_ptr_.size(); ++p) std::memcpy(&points_[3 * p], xyz_ptr_[p], 3 * sizeof(double));
+    if (cameras)
+      for (size_t c = 0; c < cam_ptr_.size(); ++c)
+        std::memcpy(&cam_params_[cam_off_[c]], cam_ptr_[c], pcd_camera_num_params(cam_model_[c]) * sizeof(double));
+  }
+
+  std::unordered_map<const double*, int> cam_index_, image_index_, point_index_;
+  std::vector<double*> cam_ptr_, qvec_ptr_, tvec_ptr_, xyz_ptr_;
+  std::vector<int32_t> cam_model_, cam_off_, image_cam_, obs_image_, obs_point_, lidar_point_;
+  std::vector<uint8_t> image_const_pose_;
+  std::vector<double> cam_params_, poses_, points_, obs_xy_, lidar_abcd_, lidar_w_;
+  size_t cam_len_ = 0, num_evaluations_ = 0;
+  HipBlockBuffers buf_;
+  pcd_ba* ba_ = nullptr;
+  bool cameras_variable_ = false, ok_ = true;
 };
 
 }  // namespace colmap_hip

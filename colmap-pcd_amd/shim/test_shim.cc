@@ -614,7 +614,8 @@ static void TestCeresBlockShapes() {
   static const double res5[5] = {1, 2, 3, 4, 5};
   buf.b.residuals = res5;
   HipReprojectionBlock var(&buf, 0, false, 4), cst(&buf, 1, true, 8);
-  HipLidarBlock lid(&buf, 2, 0);
+  buf.num_obs = 2;
+  HipLidarBlock lid(&buf, 0);
   CHECK_EQ(var.num_residuals(), 2); CHECK_EQ(cst.num_residuals(), 2); CHECK_EQ(lid.num_residuals(), 1);
   CHECK((var.parameter_block_sizes() == std::vector<int32_t>{4, 3, 3, 4}));
   CHECK((cst.parameter_block_sizes() == std::vector<int32_t>{3, 8}));
@@ -767,6 +768,56 @@ static int TestGpuCeresAdapterEndToEnd() {
   CHECK_EQ((int)pcd_ba_evaluate(fresh.handle(), &of), (int)PCD_OK);
   CHECK(r3 == res_fresh);
   CHECK_EQ(cb.num_evaluations(), 3u);
+  // ---- the recorder route (integration/colmap-pcd-hip.patch): the call sites keep creating the blocks themselves, in
+  // their own order -- first half of the reprojection blocks, then the lidar blocks, then the rest, as SetUpLocalByLidar
+  // adds the constant points' blocks behind the lidar terms -- and only the addresses of the parameter blocks are noted
+  {
+    HipBlockRecorder recd;
+    std::vector<std::unique_ptr<ceres::CostFunction>> rb(O + L);
+    auto add_obs = [&](size_t o) {
+      const int im = ba.obs_image_[o], pt = ba.obs_point_[o], cm = ba.image_cam_[im];
+      rb[o].reset(recd.AddReprojection(ba.cam_model_[cm], src.Qvec(ba.image_ids_[im]), src.Tvec(ba.image_ids_[im]),
+                                       src.XYZ(ba.point_ids_[pt]), src.Params(ba.camera_ids_[cm]), &ba.obs_xy_[2 * o],
+                                       ba.image_const_pose_[im] != 0));
+    };
+    for (size_t o = 0; o < O / 2; ++o) add_obs(o);
+    for (size_t l = 0; l < L; ++l)
+      rb[O + l].reset(recd.AddLidar(src.XYZ(ba.point_ids_[ba.lidar_point_[l]]), &ba.lidar_abcd_[4 * l], ba.lidar_w_[l]));
+    for (size_t o = O / 2; o < O; ++o) add_obs(o);
+    CHECK_EQ(recd.NumResiduals(), 2 * O + L);
+    CHECK(recd.Finalize(0, /*cameras_variable=*/true));
+    recd.PrepareForEvaluation(true, true);
+    CHECK(recd.ok());
+    cb.PrepareForEvaluation(true, true);                               // the mirror route at the same (moved) state
+    for (size_t k = 0; k < blocks.size(); ++k) {
+      Block& b = blocks[k];
+      double ra[2] = {0, 0}, rbv[2] = {0, 0};
+      std::vector<std::vector<double>> ja(b.params.size()), jb2(b.params.size());
+      std::vector<double*> pa(b.params.size(), nullptr), pb(b.params.size(), nullptr);
+      for (size_t i = 0; i < b.params.size(); ++i) {
+        const size_t n = (size_t)b.f->num_residuals() * b.f->parameter_block_sizes()[i];
+        ja[i].assign(n, -1.0); jb2[i].assign(n, -2.0);
+        if (!b.constant[i]) { pa[i] = ja[i].data(); pb[i] = jb2[i].data(); }
+      }
+      CHECK(rb[k]->parameter_block_sizes() == b.f->parameter_block_sizes());
+      CHECK(b.f->Evaluate(b.params.data(), ra, pa.data()));
+      CHECK(rb[k]->Evaluate(b.params.data(), rbv, pb.data()));
+      CHECK(ra[0] == rbv[0] && (b.f->num_residuals() == 1 || ra[1] == rbv[1]));
+      for (size_t i = 0; i < b.params.size(); ++i)
+        if (!b.constant[i]) CHECK(ja[i] == jb2[i]);
+    }
+    // in-place moves are picked up through the recorded addresses
+    rec.points3D[9].xyz[0] += 0.01;
+    recd.PrepareForEvaluation(false, true);
+    cb.PrepareForEvaluation(false, true);
+    double ra[2], rbv[2];
+    for (size_t k = 0; k < blocks.size(); ++k) {
+      CHECK(blocks[k].f->Evaluate(blocks[k].params.data(), ra, nullptr) && rb[k]->Evaluate(blocks[k].params.data(), rbv, nullptr));
+      CHECK(ra[0] == rbv[0]);
+    }
+    HipBlockRecorder empty;
+    CHECK(!empty.Finalize(0, false));                                  // no residuals: Solve returns false (:489-491)
+  }
   // run-time switch
   setenv("COLMAP_PCD_HIP", "0", 1);
   CHECK(!HipBackendEnabled());
