@@ -193,6 +193,7 @@ pcd_status pcd_associate_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q,
                                 uint64_t max_range_count, int gate_mode, const uint64_t* d_keys_in,
                                 const pcd_assoc_out* d_out, void* stream) {
   PCD_REQUIRE(c && d_out, "null pointer");
+  PCD_REFUSE_CAPTURE(stream);
   const bool bounded = (gate_mode & PCD_GATE_BOUNDED_SEARCH) != 0;
   gate_mode &= ~PCD_GATE_BOUNDED_SEARCH;
   PCD_REQUIRE(gate_mode >= 0 && gate_mode <= 2, "gate_mode");
@@ -227,6 +228,7 @@ pcd_status pcd_associate_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q,
 pcd_status pcd_nn_winner_payload_device(pcd_cloud* c, const uint64_t* d_keys, uint64_t Q, int32_t* d_payload,
                                         void* stream) {
   PCD_REQUIRE(c && (Q == 0 || (d_keys && d_payload)), "null pointer");
+  PCD_REFUSE_CAPTURE(stream);
   if (Q == 0) return PCD_OK;
   PCD_HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
@@ -241,6 +243,7 @@ pcd_status pcd_associate_from_payload_device(int device, const double* d_q_xyz, 
                                              uint64_t max_range_count, int gate_mode, const uint64_t* d_keys,
                                              const int32_t* d_payload, const pcd_assoc_out* d_out, void* stream) {
   PCD_REQUIRE(d_out && (Q == 0 || (d_q_xyz && d_keys && d_payload)), "null pointer");
+  PCD_REFUSE_CAPTURE(stream);
   PCD_REQUIRE(gate_mode >= 0 && gate_mode <= 2, "gate_mode");
   PCD_REQUIRE(gate_mode == PCD_GATE_CONTROLLER || (d_max_range && (max_range_count == 1 || max_range_count == Q)),
               "max_range must have 1 or Q entries");
@@ -259,6 +262,7 @@ pcd_status pcd_filter_lidar_outlier_device(int device, const double* d_points_xy
                                            const uint8_t* d_type, uint64_t n, double max_proj_dist_error,
                                            double max_icp_dist_error, uint8_t* d_erase, void* stream) {
   PCD_REQUIRE(n == 0 || (d_points_xyz && d_lidar_xyz && d_type && d_erase), "null pointer");
+  PCD_REFUSE_CAPTURE(stream);
   if (n == 0) return PCD_OK;
   PCD_TRY(require_device(device));
   hipStream_t s = (hipStream_t)stream;

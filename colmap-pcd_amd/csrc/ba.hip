@@ -1128,6 +1128,7 @@ pcd_status pcd_ba_device_parameters(pcd_ba* b, double** d_poses, double** d_poin
 
 pcd_status pcd_ba_evaluate_device(pcd_ba* b, const pcd_ba_out* o, void* stream) {
   PCD_REQUIRE(b && o, "null pointer");
+  PCD_REFUSE_CAPTURE(stream);
   PCD_HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
   const BaDev d = b->dev();
@@ -1193,6 +1194,7 @@ pcd_status pcd_ba_evaluate_device(pcd_ba* b, const pcd_ba_out* o, void* stream) 
 
 pcd_status pcd_ba_observation_errors_device(pcd_ba* b, double* d_sq_err, double* d_depth, void* stream) {
   PCD_REQUIRE(b, "null handle");
+  PCD_REFUSE_CAPTURE(stream);
   if (!b->O || (!d_sq_err && !d_depth)) return PCD_OK;
   PCD_HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1219,6 +1221,7 @@ pcd_status pcd_ba_observation_errors(pcd_ba* b, double* sq_err, double* depth) {
 
 pcd_status pcd_ba_filter_tracks_device(pcd_ba* b, double max_reproj_error, const pcd_ba_filter_out* o, void* stream) {
   PCD_REQUIRE(b && o, "null pointer");
+  PCD_REFUSE_CAPTURE(stream);
   PCD_HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
   const uint64_t O = b->O;

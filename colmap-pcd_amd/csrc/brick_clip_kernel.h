@@ -202,16 +202,26 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
     const uint4 it2 = items[PCD_UNI(min(item + 2 * stride, item_end - 1))];
 
     const uint32_t cnt = (uint32_t)item_count(it0);
-    float qx[G], qy[G], qz[G];   // wave-uniform, held in VGPRs (brick_kernel.h)
+    // The item's queries as wave-uniform values in VGPRs (an SGPR operand halves the VALU rate: brick_kernel.h).  Through
+    // LDS: every lane writes its record (lanes >= cnt hold a copy of the last query) into the first tile buffer -- free
+    // between two items' tiles -- and all lanes read the first 8 records back, 12 bytes each, same address for the whole
+    // wavefront (a broadcast).  One ds_write_b128 + 8 ds_read_b96 on the LDS port instead of 24 v_readlane + 24 v_mov
+    // on the VALU and a branch per query slot.
+    float qx[G], qy[G], qz[G];
+    {
+      typedef float f32x3 __attribute__((ext_vector_type(3)));
+      const uint32_t qb = lds_addr(s_tile[wave][0]);
+      const f32x4 qrec = {m0.q.x, m0.q.y, m0.q.z, m0.q.w};
+      f32x3 qv[G];
+      asm volatile("ds_write_b128 %9, %8\n\ts_waitcnt lgkmcnt(0)\n\t"
+                   "ds_read_b96 %0, %10\n\tds_read_b96 %1, %10 offset:16\n\tds_read_b96 %2, %10 offset:32\n\t"
+                   "ds_read_b96 %3, %10 offset:48\n\tds_read_b96 %4, %10 offset:64\n\tds_read_b96 %5, %10 offset:80\n\t"
+                   "ds_read_b96 %6, %10 offset:96\n\tds_read_b96 %7, %10 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(qv[0]), "=&v"(qv[1]), "=&v"(qv[2]), "=&v"(qv[3]), "=&v"(qv[4]), "=&v"(qv[5]), "=&v"(qv[6]), "=&v"(qv[7])
+                   : "v"(qrec), "v"(qb + (uint32_t)lane * 16u), "v"(qb)
+                   : "memory");
 #pragma unroll
-    for (int k = 0; k < G; ++k) {
-      if (k == 0 || k < (int)cnt) {
-        asm volatile("v_mov_b32 %0, %1" : "=v"(qx[k]) : "s"(readlane_f(m0.q.x, k)));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(qy[k]) : "s"(readlane_f(m0.q.y, k)));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(qz[k]) : "s"(readlane_f(m0.q.z, k)));
-      } else {
-        qx[k] = qy[k] = qz[k] = 0.f;
-      }
+      for (int k = 0; k < G; ++k) { qx[k] = qv[k].x; qy[k] = qv[k].y; qz[k] = qv[k].z; }
     }
     const int bx = (int)it0.y, by = (int)it0.z, bz = (int)(it0.w & 0x0FFFFFFFu);
     double best[G];

@@ -66,6 +66,25 @@ const char* get_error();
 // Checks that `device` exists and is a gfx950 part.  No CPU fallback exists.
 pcd_status require_device(int device);
 
+// The *_device entry points are written for EAGER launches on the caller's stream: they grow per-handle scratch
+// (hipFree + hipMalloc), build per-cloud tables behind a hipStreamSynchronize on first use and time scopes with
+// events.  None of that may be recorded into a graph -- a replay would write through scratch addresses a later eager
+// call has freed (the memory fault seen when round 3's step was captured with torch.cuda.graph and replayed) -- so a
+// capturing stream is refused before anything is touched.  (Asking about the legacy stream while another stream of
+// the device captures in global mode is an error of the caller's; it is reported the same way.)
+inline pcd_status refuse_capture(hipStream_t s, const char* fn) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  const hipError_t e = hipStreamIsCapturing(s, &st);
+  if (e != hipSuccess || st != hipStreamCaptureStatusNone) {
+    if (e != hipSuccess) (void)hipGetLastError();
+    set_error("%s: the stream is capturing a graph; this entry point allocates scratch and may synchronise, "
+              "it can only be launched eagerly", fn);
+    return PCD_ERR_UNSUPPORTED;
+  }
+  return PCD_OK;
+}
+#define PCD_REFUSE_CAPTURE(stream) PCD_TRY(::pcd::refuse_capture((hipStream_t)(stream), __func__))
+
 // ------------------------------------------------------- device buffers ----
 template <typename T>
 struct DevBuf {

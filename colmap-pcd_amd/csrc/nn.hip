@@ -1145,6 +1145,7 @@ pcd_status pcd_nn_query_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q, 
                                void* stream) {
   PCD_REQUIRE(c, "null cloud");
   PCD_REQUIRE(Q == 0 || (d_q_xyz && d_keys), "null pointer");
+  PCD_REFUSE_CAPTURE(stream);
   PCD_HIP_TRY(hipSetDevice(c->device));
   return nn_device(c, d_q_xyz, Q, algo, d_keys, (hipStream_t)stream);
 }
@@ -1153,6 +1154,7 @@ pcd_status pcd_nn_refine_device(pcd_cloud* c, const double* d_q_xyz, uint64_t Q,
                                 uint64_t* d_keys, void* stream) {
   PCD_REQUIRE(c, "null cloud");
   PCD_REQUIRE(Q == 0 || (d_q_xyz && d_keys), "null pointer");
+  PCD_REFUSE_CAPTURE(stream);
   PCD_HIP_TRY(hipSetDevice(c->device));
   return nn_device(c, d_q_xyz, Q, PCD_NN_AUTO, d_keys, (hipStream_t)stream, /*refine=*/true, d_skip);
 }

@@ -693,6 +693,7 @@ pcd_status pcd_sift_match_device(int device, const uint8_t* d_desc1, int n1, con
                                  int32_t* d_m21, uint32_t* d_matches, int32_t* d_num_matches, void* stream) {
   return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(n1 >= 0 && n2 >= 0 && d_num_matches, "sizes / count pointer");
+  PCD_REFUSE_CAPTURE(stream);
   PCD_TRY(require_device(device));
   hipStream_t s = (hipStream_t)stream;
   if (n1 == 0 || n2 == 0) {   // MatchSiftFeaturesCPU with an empty set: no matches (sift_test.cc:311-318)
@@ -752,6 +753,7 @@ pcd_status pcd_sift_match_batch_device(int device, const uint8_t* d_arena, const
                                        int32_t* d_counts, void* stream) {
   return pcd::guard([&]() -> pcd_status {
   PCD_REQUIRE(n_images >= 0 && n_pairs >= 0 && first_row, "sizes / first_row");
+  PCD_REFUSE_CAPTURE(stream);
   if (n_pairs == 0) return PCD_OK;
   PCD_REQUIRE(pairs && match_offset && d_counts && d_matches, "null pointer");
   PCD_REQUIRE(first_row[n_images] == 0 || d_arena, "null arena");

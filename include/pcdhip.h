@@ -16,6 +16,11 @@
  *     a time; different handles are independent;
  *   - `stream` arguments are hipStream_t passed as void* (NULL = default
  *     stream); _device calls are asynchronous on that stream;
+ *   - _device calls are EAGER launches: they grow per-handle scratch, build
+ *     per-cloud tables on first use and may synchronise the stream, so they
+ *     cannot be recorded into a HIP graph.  A stream that is capturing
+ *     (hipStreamBeginCapture, torch.cuda.graph) is refused with
+ *     PCD_ERR_UNSUPPORTED before anything is allocated or launched;
  *   - there is NO CPU fallback: without a usable gfx950 device every entry
  *     point that computes returns PCD_ERR_NO_DEVICE.
  */
