@@ -70,12 +70,39 @@ def launch_ranks(a):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
+    # Poll the ranks: a rank that dies (import error, OOM, a failed assert) leaves the others in init_process_group or
+    # a collective until the RCCL timeout -- on the first non-zero exit, or at the deadline, the rest are terminated.
+    # This parent has made no GPU call, so ending children is all the recovery there is to do.
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("PCD_BENCH_DEADLINE_S", "3000"))
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = f"rank {bad[0]} exited with {rcs[bad[0]]}" if bad else "deadline reached"
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 10
+            while time.time() < t_kill and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    reader.join(timeout=10)
+    sys.stdout.write((out0[0] if out0 else b"").decode())
     sys.stdout.flush()
-    if any(rcs):
-        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+    if failed or any(rcs):
+        sys.stderr.write(f"bench.py: {failed or 'a rank failed'}; rank exit codes {rcs}\n")
         sys.exit(1)
     sys.exit(0)
 
@@ -108,7 +135,7 @@ PER_QUERY_BYTES = 20             # 12 B query in + 8 B key out
 def source_hash():
     """hash of the NN kernel sources: profiles/traffic.json is only quoted when it was measured on these"""
     h = hashlib.sha256()
-    for f in ("nn.hip", "brick_kernel.h", "grid.h", "cloud.hip"):
+    for f in ("nn.hip", "brick_kernel.h", "brick_clip_kernel.h", "grid.h", "cloud.hip", "ba.hip", "ba_math.h", "ba_cam_jac.h"):
         with open(os.path.join(ROOT, "colmap-pcd_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -523,18 +550,80 @@ def main():
         brick_ms = per.get("nn_brick", float("nan"))
         staged = st["staged_points"]
         alg_bytes = staged * POINT_BYTES + PER_QUERY_BYTES * Q
-        achieved = alg_bytes / (brick_ms * 1e-3) / 1e9
         rec_achieved = (staged * REC_BYTES + PER_QUERY_BYTES * Q) / (brick_ms * 1e-3) / 1e9
-        traffic, hbm_frac, tnote = None, None, "profiles/traffic.json absent"
+        # PMC numbers (HBM-side bytes, VALU wave-instructions) come from tools/prof_bench.sh passes of this same command,
+        # kept in profiles/traffic.json with the hash of the kernel sources they were measured on; they are quoted only
+        # when that hash matches the sources in this tree (rocprofv3 cannot run inside the timed run).
+        tj, tnote = {}, "profiles/traffic.json absent"
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             tj = json.load(open(tp))
             if tj.get("source_hash") == source_hash() and tj.get("workload") == [a.cloud, Qtot] and world == 1:
-                traffic = tj.get("nn_brick_bytes_per_launch")
-                hbm_frac = traffic / (brick_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                tnote = "PMC (2*FETCH_SIZE + WRITE_SIZE) per launch from tools/prof_bench.sh on these kernel sources"
+                tnote = ("PMC per launch (2*FETCH_SIZE + WRITE_SIZE; SQ_INSTS_VALU) from tools/prof_bench.sh on these "
+                         "kernel sources, profiles/traffic.json")
             else:
-                tnote = "profiles/traffic.json was measured on other kernel sources / another workload: not quoted"
+                tj, tnote = {}, "profiles/traffic.json was measured on other kernel sources / another workload: not quoted"
+
+        def pmc(kernel, field):
+            for name, rec in tj.get("kernels", {}).items():
+                if kernel in name and rec.get(field) is not None:
+                    return rec[field]
+            return None
+
+        def entry(kernel, scope, bound, alg_bytes_, what, **extra):
+            """one kernel against the HBM roofline on its SURVEY 8d bytes; `traffic` = PMC bytes per launch"""
+            ms = per.get(scope)
+            if ms is None:
+                return None
+            ach = alg_bytes_ / (ms * 1e-3) / 1e9
+            tr = pmc(kernel, "bytes_per_launch")
+            e = dict(kernel=kernel, bound=bound, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                     traffic=tr, launch_ms=ms, algorithmic_bytes=alg_bytes_, algorithmic_bytes_def=what)
+            if tr is not None:
+                e["hbm_frac"] = tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                e["traffic_over_algorithmic"] = tr / alg_bytes_
+            e.update(extra)
+            return e
+
+        pairs = st["pair_evals"]
+        valu = pmc("k_nn_brick", "valu_wave_instructions")
+        brick = entry("k_nn_brick_clip", "nn_brick", "valu-issue", alg_bytes,
+                      "12 B x staged points (counted by the kernel's statistics pass) + 20 B x queries",
+                      staged_points=staged, brick_groups=st["brick_groups"], pair_evals=pairs,
+                      pair_evals_per_query=pairs / max(Q, 1), pairs_per_sec=pairs / (brick_ms * 1e-3),
+                      compare_valu_wave_instructions=pairs / 64 * 9, valu_wave_instructions=valu,
+                      compare_share_of_valu=(pairs / 64 * 9 / valu) if valu else None,
+                      # 8 full-rate + 1 half-rate VALU per pair on 1024 SIMDs at the measured 1.03 / 1.9 ns per
+                      # wave-instruction (profiles/r02_ubench_valu_rate.txt, profiles/r04_ubench_cmp_block.txt)
+                      compare_floor_ms=pairs / 64 * (8 * 1.03 + 1.9) * 1e-6 / 1024,
+                      frac_16B_records=rec_achieved / HBM_PEAK_GBS, compulsory_bytes=12 * a.cloud + PER_QUERY_BYTES * Q,
+                      note="VALU-issue-bound, not HBM-bound (DESIGN.md section 5): `frac` is SURVEY 8d's algorithmic "
+                           "figure (staged points are re-read from L2 / MALL: it can exceed the fabric share), "
+                           "`hbm_frac` the PMC share of HBM peak; the kernel's own measure is pairs_per_sec against "
+                           "compare_floor_ms")
+        fb_bytes = st["fallback_points"] * POINT_BYTES + PER_QUERY_BYTES * st["fallback_queries"]
+        kernels = {
+            "k_nn_brick_clip": brick,
+            "k_nn_fallback": entry("k_nn_fallback", "nn_fallback", "latency (dependent walk steps)", fb_bytes,
+                                   "12 B x leaf points scanned + 20 B x fallback queries (scope includes k_fb_compact)",
+                                   fallback_queries=st["fallback_queries"], fallback_points=st["fallback_points"]),
+            "k_ba_images": entry("k_ba_images", "ba_images_w", "hbm", 200 * O,
+                                 "SURVEY 8d Jacobian pass: 200 B per observation (16 obs + 12 indices + point + 144 B of W)"),
+            "k_ba_points": entry("k_ba_points", "ba_points", "latency (gathers at 4 waves/SIMD)", 84 * O + 96 * P + 100 * L,
+                                 "84 B per observation (16 obs + 12 indices + 56 pose) + 96 B of point blocks per "
+                                 "track + SURVEY 8d's 100 B per lidar term"),
+            "k_ba_cost": entry("k_ba_cost", "ba_points_cost", "hbm", 44 * O + 76 * L,
+                               "SURVEY 8d residual-only pass: 44 B per observation + 76 B per lidar term"),
+        }
+        sb = extras.get("sift_block")
+        if sb:
+            kernels["k_sift_scores_batch"] = dict(kernel="k_sift_scores_batch (+ finalize, compaction)", bound="mfma",
+                                                  achieved=sb["useful_TOPs"], peak=5000.0, unit="TOP/s",
+                                                  frac=sb["useful_frac_of_dense_i8_peak"], traffic=None,
+                                                  launch_ms=sb["ms"], algorithmic_flops_def="2 x 128 x n1 x n2 per pair")
+        kernels = {k: v for k, v in kernels.items() if v}
+        ba_alg = (200 + 44) * O + (100 + 76) * L
+        traffic, hbm_frac = brick.get("traffic"), brick.get("hbm_frac")
         out = {
             "metric": "NN queries/sec + BA-iter ms, 10M-pt cloud / 1M 3D feats",
             "value": Qtot / (dt / a.steps),
@@ -552,17 +641,12 @@ def main():
             "ba_iter_ms": ba_ms,
             "ba_iter_def": "normal-equation pass (cost, H_img, g_img, H_pt, g_pt, W) + cost-only pass, kernel time of rank 0",
             "kernel_ms": {k: round(v, 4) for k, v in sorted(per.items())},
-            "roofline": {"bound": "hbm", "kernel": "k_nn_brick", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "hbm_frac": hbm_frac, "traffic_note": tnote,
-                         "algorithmic_bytes": alg_bytes, "bytes_per_staged_point": POINT_BYTES,
-                         "frac_16B_records": rec_achieved / HBM_PEAK_GBS, "launch_ms": brick_ms,
-                         "staged_points": staged, "brick_groups": st["brick_groups"],
-                         "fallback_queries": st["fallback_queries"], "fallback_points": st["fallback_points"],
-                         "pair_evals": st["pair_evals"],
-                         "compulsory_bytes": 12 * a.cloud + PER_QUERY_BYTES * Q,
-                         "note": "the kernel is VALU-bound, not HBM-bound (DESIGN.md section 5): frac is SURVEY 8d's "
-                                 "algorithmic figure, hbm_frac the measured HBM share; compare kernels by launch_ms"},
+            # top level: the dominant kernel (the keys the driver parses); every kernel of the step under "kernels"
+            "roofline": dict(brick, traffic_note=tnote, kernels=kernels,
+                             ba_iteration=dict(algorithmic_bytes=ba_alg, ms=ba_ms,
+                                               frac=ba_alg / (ba_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ba_ms else None,
+                                               definition="SURVEY 8d: (200 + 44) B per observation + (100 + 76) B per "
+                                                          "lidar term over both passes of one iteration")),
         }
         out.update(extras)
         if cs:

@@ -16,7 +16,7 @@ cd $R
 python3 tools/prof_summary.py $out k_nn_ k_ba_ k_bk_ k_fb_ k_brick k_associate k_prepare k_finalize k_query > $out/summary.txt 2>&1
 python3 tools/make_traffic.py $out 10000000 1000000 > $out/traffic.log 2>&1
 cp profiles/traffic.json $out/traffic.json
-find $out -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 find $out -name "*counter_collection.csv" -delete; find $out -name "*kernel_trace.csv" -delete
 find $out -name "*agent_info.csv" -delete; find $out -name "*domain_stats.csv" -delete
 head -c 3000 $out/summary.txt
