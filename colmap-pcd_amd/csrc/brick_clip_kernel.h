@@ -15,7 +15,7 @@
 //             the masks of the item's queries are OR-ed (three DPP steps) and become wave-uniform scalars;
 //   stage B   of every quad row only the hull of its masked x cells is staged (the centre row without the cells of
 //             stage A); rows the balls do not touch are dropped.  The ranges come from ONE table per item -- lane
-//             NK row + k holds cell_start at x boundary k of quad row `row` (63 loads in one instruction, prefetched
+//             7 row + k holds cell_start at x boundary k of quad row `row` (63 loads in one instruction, prefetched
 //             an item ahead) -- so clipping costs no dependent memory access: v_readlane with a scalar lane index.
 //
 // Exactness.  Every point that is not compared lies (a) outside the region -- the region bound of nn.hip's header
@@ -29,9 +29,8 @@
 
 namespace pcd {
 
+constexpr int kClipNk = 7;      // x boundaries of a region row: cells 2 bx - 2 .. 2 bx + 4
 constexpr int kClipRows = 9;    // quad rows of the region: (by - 1 .. by + 1) x (bz - 1 .. bz + 1)
-// (a brick is BX cells long in x -- a template parameter of the kernel -- and one cell quad in (y, z); a region row has
-//  BX + 4 cells = BX + 5 x boundaries: cells BX bx - 2 .. BX bx + BX + 2)
 constexpr int kATile = 128;     // points stage A stages at most (2 DMA instructions); the rest of the brick's range joins stage B
 constexpr int kClipRanges = 10; // 8 halo rows + the centre row's left and right parts
 #ifdef PCD_ABLATE   // timing-only ablations (tools/nn_ablate.py; results are wrong): brick_kernel.h
@@ -92,40 +91,29 @@ __device__ __forceinline__ float proven_bound_f(const GridParams& g, float qx, f
 struct ClipMeta {    // per-item loads issued one item ahead
   float4 q;          // lane < cnt: query (x, y, z, bits(query id))
   uint64_t prior;    // lane < cnt: the key the query came with
-  uint32_t bnd;      // lane NK row + k: cell_start at x boundary k of region row `row` (0 for rows outside the grid)
-  uint32_t bnd2;     // BX > 2: entries 64 .. 9 NK - 1 of the same table in lanes 0 ..
+  uint32_t bnd;      // lane 7 row + k: cell_start at x boundary k of region row `row` (0 for rows outside the grid)
 };
 
-// one entry of the boundary table; lpos = the entry's place, k | ry << 8 | rz << 16 (rz >= 3: no such row)
-template <int BX>
-__device__ __forceinline__ uint32_t clip_boundary(const GridParams& g, int bx, int by, int bz,
-                                                  const uint32_t* __restrict__ cell_start, uint32_t lpos) {
-  const int lk = (int)(lpos & 0xFFu), lry = (int)((lpos >> 8) & 0xFFu), lrz = (int)(lpos >> 16);
-  const int yq = by - 1 + lry, zq = bz - 1 + lrz;
-  const bool ok = lrz < 3 && yq >= 0 && yq < g.qdims[0] && zq >= 0 && zq < g.qdims[1];
-  const int x = min(max(BX * bx - 2 + lk, 0), g.dims[0]);
-  const uint32_t v = cell_start[quad_row_base(g, ok ? yq : 0, ok ? zq : 0) + 4u * (uint64_t)x];
-  return ok ? v : 0u;
-}
-
-// lpos / lpos2: the places of the lane's one or two table entries
-template <int BX>
+// lpos: the lane's place in the boundary table, k | ry << 8 | rz << 16 (rz == 3: no such row)
 __device__ __forceinline__ ClipMeta clip_load_meta(const GridParams& g, const uint4 it, const float4* __restrict__ qsorted,
                                                    const uint64_t* __restrict__ ksorted,
-                                                   const uint32_t* __restrict__ cell_start, uint32_t lpos, uint32_t lpos2) {
+                                                   const uint32_t* __restrict__ cell_start, uint32_t lpos) {
   const int lane = threadIdx.x & 63;
+  const int lk = (int)(lpos & 0xFFu), lry = (int)((lpos >> 8) & 0xFFu), lrz = (int)(lpos >> 16);
   ClipMeta m;
   // every lane issues every load (clamped indices, results masked afterwards): brick_kernel.h brick_load_meta
   const int cnt = item_count(it);   // >= 1
   m.q = qsorted[it.x + (lane < cnt ? lane : cnt - 1)];
   m.prior = ksorted[it.x + (lane < cnt ? lane : cnt - 1)];
   const int bx = (int)it.y, by = (int)it.z, bz = (int)(it.w & 0x0FFFFFFFu);
-  m.bnd = clip_boundary<BX>(g, bx, by, bz, cell_start, lpos);
-  m.bnd2 = 9 * (BX + 5) > 64 ? clip_boundary<BX>(g, bx, by, bz, cell_start, lpos2) : 0u;
+  const int yq = by - 1 + lry, zq = bz - 1 + lrz;
+  const bool ok = lrz < 3 && yq >= 0 && yq < g.qdims[0] && zq >= 0 && zq < g.qdims[1];
+  const int x = min(max(2 * bx - 2 + lk, 0), g.dims[0]);
+  const uint32_t v = cell_start[quad_row_base(g, ok ? yq : 0, ok ? zq : 0) + 4u * (uint64_t)x];
+  m.bnd = ok ? v : 0u;
   return m;
 }
 
-template <int BX>
 __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const float4* __restrict__ sorted,
                                                           const uint32_t* __restrict__ cell_start,
                                                           const float4* __restrict__ qsorted,
@@ -134,8 +122,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ fb_list,
                                                           uint32_t* __restrict__ fb_count, int flags) {
   constexpr int G = 8;
-  constexpr int NK = BX + 5, NC = BX + 4;   // x boundaries / cells of a region row
-  static_assert(BX >= 2 && BX <= 4, "mask fields of 8 bits per row, table of at most 128 entries");
+  constexpr int NK = kClipNk, NC = kClipNk - 1;   // x boundaries / cells of a region row
   const int collect_stats = flags & 1;
   const bool no_clip = (flags & 2) != 0;   // A/B switch: stage the whole region in stage B (results identical)
   __shared__ __attribute__((aligned(16))) float4 s_tile[4][2][kTile];
@@ -147,18 +134,15 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
   unsigned long long st_staged = 0, st_pairs = 0, st_groups = 0;
   uint32_t fb_base = 0, fb_left = 0;
   // the lane's place in the boundary table
-  uint32_t lpos, lpos2;
+  uint32_t lpos;
   {
-    auto place = [](int e) {   // entry e of the table: row e / NK (rows >= 9: rz >= 3, "no such row"), boundary e % NK
-      const int lrow = e / NK, lk = e - NK * lrow, lrz = lrow / 3, lry = lrow - 3 * lrz;
-      return (uint32_t)lk | ((uint32_t)lry << 8) | ((uint32_t)lrz << 16);
-    };
-    lpos = place(lane);
-    lpos2 = place(lane + 64);
-    asm volatile("" : "+v"(lpos), "+v"(lpos2));   // one register each; not three hoisted ones
+    const int lrow = (lane * 9363) >> 16, lk = lane - 7 * lrow;   // lane / 7 for lane < 64
+    const int lrz = (lrow * 21846) >> 16, lry = lrow - 3 * lrz;   // lrow / 3 (lane 63: row 9 = (0, 3), not a row)
+    lpos = (uint32_t)lk | ((uint32_t)lry << 8) | ((uint32_t)lrz << 16);
+    asm volatile("" : "+v"(lpos));   // one register; not three hoisted ones
   }
   // entry e of the table of item metadata m (e wave-uniform)
-#define PCD_BND(m, e) (9 * NK > 64 && (e) >= 64 ? PCD_RL((m).bnd2, (e) - 64) : PCD_RL((m).bnd, (e)))
+#define PCD_BND(m, e) PCD_RL((m).bnd, (e))
 
   // XCD-aware work split (brick_kernel.h): blocks b, b+8, ... walk their own contiguous eighth of the item list
   uint32_t item, item_end, stride;
@@ -180,7 +164,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
   // DMA instructions (lanes past the range re-read its last record; an empty range reads the record at its start,
   // which exists -- `sorted` ends with spare records -- and is not compared)
   auto issue_a = [&](const ClipMeta& m) {
-    const uint32_t sA = PCD_BND(m, 4 * NK + 2), eA = PCD_BND(m, 4 * NK + 2 + BX);
+    const uint32_t sA = PCD_BND(m, 4 * NK + 2), eA = PCD_BND(m, 4 * NK + 4);
     const uint32_t nA = min(eA - sA, (uint32_t)kATile);
     const uint32_t last = nA ? nA - 1u : 0u;
     const uint32_t i0 = sA + min((uint32_t)lane, last), i1 = sA + min((uint32_t)lane + 64u, last);
@@ -189,7 +173,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
   };
 
   uint4 it0 = items[PCD_UNI(item)];
-  ClipMeta m0 = clip_load_meta<BX>(g, it0, qsorted, ksorted, cell_start, lpos, lpos2);
+  ClipMeta m0 = clip_load_meta(g, it0, qsorted, ksorted, cell_start, lpos);
   uint4 it1 = items[PCD_UNI(min(item + stride, item_end - 1))];
   issue_a(m0);
 
@@ -198,7 +182,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     // ---- prefetch: metadata of the next item, item record of the one after (clamped to the last item) ----
-    const ClipMeta m1 = clip_load_meta<BX>(g, it1, qsorted, ksorted, cell_start, lpos, lpos2);
+    const ClipMeta m1 = clip_load_meta(g, it1, qsorted, ksorted, cell_start, lpos);
     const uint4 it2 = items[PCD_UNI(min(item + 2 * stride, item_end - 1))];
 
     const uint32_t cnt = (uint32_t)item_count(it0);
@@ -229,7 +213,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
     for (int k = 0; k < G; ++k) best[k] = __builtin_bit_cast(double, kKeyInit);
 
     // ---- stage A: the brick's own cells ----------------------------------------------------------------------
-    const uint32_t sA = PCD_BND(m0, 4 * NK + 2), eA = PCD_BND(m0, 4 * NK + 2 + BX);
+    const uint32_t sA = PCD_BND(m0, 4 * NK + 2), eA = PCD_BND(m0, 4 * NK + 4);
     const uint32_t nA = min(eA - sA, (uint32_t)kATile);
     if (nA > 0 && !(flags & kAblateStageA)) {
       f32x4 pa[2];
@@ -273,7 +257,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
     // ---- clip: mask of the (row, x cell) pairs the balls of the item's queries touch --------------------------
     uint32_t w0 = 0, w1 = 0, w2 = 0;   // z slab 0 / 1 / 2: bit 6 ry + k
     if (flags & kAblateClipMath) {
-      w0 = w1 = w2 = lane < (int)cnt ? 0x10101u * ((1u << NC) - 1u) : 0u;
+      w0 = w1 = w2 = lane < (int)cnt ? 0x3FFFFu : 0u;
     } else if (lane < (int)cnt) {
       // radius: sqrt(d) widened by 1e-5 (v_sqrt_f32's 1 ulp, the roundings of FLANN's sum) + the rounding of q -+ r
       // (half an ulp of |q| + r: 2.4e-7 |q| covers it four times over).  Cells in float: t = (p - origin) / h as the
@@ -285,15 +269,15 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
       const float tx0 = floorf((m0.q.x - r - g.origin[0]) * g.inv_h), tx1 = floorf((m0.q.x + r - g.origin[0]) * g.inv_h);
       const float ty0 = floorf((m0.q.y - r - g.origin[1]) * g.inv_h * 0.5f), ty1 = floorf((m0.q.y + r - g.origin[1]) * g.inv_h * 0.5f);
       const float tz0 = floorf((m0.q.z - r - g.origin[2]) * g.inv_h * 0.5f), tz1 = floorf((m0.q.z + r - g.origin[2]) * g.inv_h * 0.5f);
-      const float fx = (float)(BX * bx - 2), fy = (float)(by - 1), fz = (float)(bz - 1);
+      const float fx = (float)(2 * bx - 2), fy = (float)(by - 1), fz = (float)(bz - 1);
       const uint32_t kx0 = (uint32_t)__builtin_amdgcn_fmed3f(tx0 - fx, 0.f, (float)(NC - 1)), kx1 = (uint32_t)__builtin_amdgcn_fmed3f(tx1 - fx, 0.f, (float)(NC - 1));
       const uint32_t ry0 = (uint32_t)__builtin_amdgcn_fmed3f(ty0 - fy, 0.f, 2.f), ry1 = (uint32_t)__builtin_amdgcn_fmed3f(ty1 - fy, 0.f, 2.f);
       const uint32_t rz0 = (uint32_t)__builtin_amdgcn_fmed3f(tz0 - fz, 0.f, 2.f), rz1 = (uint32_t)__builtin_amdgcn_fmed3f(tz1 - fz, 0.f, 2.f);
       const uint32_t xm = (2u << kx1) - (1u << kx0);                     // bits kx0 .. kx1
       const uint32_t ym = (2u << ry1) - (1u << ry0), zm = (2u << rz1) - (1u << rz0);
-      const uint32_t pat = xm * ((ym * 0x4081u) & 0x10101u);             // the x mask in the 8-bit fields of the rows ry0 .. ry1
+      const uint32_t pat = xm * ((ym * 0x421u) & 0x1041u);               // the x mask in the 6-bit fields of the rows ry0 .. ry1
       w0 = (zm & 1u) ? pat : 0u; w1 = (zm & 2u) ? pat : 0u; w2 = (zm & 4u) ? pat : 0u;
-      if (no_clip) w0 = w1 = w2 = 0x10101u * ((1u << NC) - 1u);
+      if (no_clip) w0 = w1 = w2 = 0x3FFFFu;
     }
     // OR over lanes 0..7 (row_shr 1, 2, 4; lanes without a source contribute 0): lane 7 holds the item's mask
 #define PCD_OR_SHR(v, ctrl) v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xf, 0xf, true)
@@ -306,7 +290,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
     uint32_t rs[kClipRanges], rl[kClipRanges];
 #pragma unroll
     for (int r = 0; r < kClipRows; ++r) {
-      const uint32_t xm = (M[r / 3] >> (8 * (r % 3))) & 0xFFu;
+      const uint32_t xm = (M[r / 3] >> (6 * (r % 3))) & 63u;
       const int k0 = xm ? __builtin_ctz(xm) : 0, k1 = xm ? 32 - __builtin_clz(xm) : 0;   // cells k0 .. k1 - 1
       const uint32_t s = PCD_BND(m0, r * NK + k0), e = PCD_BND(m0, r * NK + k1);
       if (r == 4) {
@@ -397,8 +381,8 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
     bool unproven = false;
     if (lane < (int)cnt) {
       const uint32_t my_qi = __float_as_uint(m0.q.w);
-      const int c0[3] = {max(BX * bx - 2, 0), max(2 * by - 2, 0), max(2 * bz - 2, 0)};
-      const int c1[3] = {min(BX * bx + BX + 2, g.dims[0]), min(2 * by + 4, g.dims[1]), min(2 * bz + 4, g.dims[2])};
+      const int c0[3] = {max(2 * bx - 2, 0), max(2 * by - 2, 0), max(2 * bz - 2, 0)};
+      const int c1[3] = {min(2 * bx + 4, g.dims[0]), min(2 * by + 4, g.dims[1]), min(2 * bz + 4, g.dims[2])};
       const float bound = (flags & kAblateBound) ? 3e38f : proven_bound_f(g, m0.q.x, m0.q.y, m0.q.z, c0, c1);
       unproven = !(__uint_as_float((uint32_t)(mine >> 32)) < bound) && !(flags & kAblateFallback);
       keys[my_qi] = mine;

@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
 // the hardware's workgroup dispatch as the load balancer (query costs spread 1:4).  2048 / 4096 / 16384 / 65536
 // workgroups: 0.384 / 0.387 / 0.368 / 0.369 ms at workload M, 0.136 / 0.125 / 0.126 / 0.125 ms on an eighth of it.
 constexpr unsigned g_fb_max_blocks = 16384;
-static int g_brick_B = 2, g_brick_R = 2, g_brick_Bx = 0 /* 0: = B */, g_collect_stats = 0, g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
+static int g_brick_B = 2, g_brick_R = 2, g_collect_stats = 0, g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
 // first stage of the grid path: 0 = the clipped brick kernel (brick_clip_kernel.h; needs the default brick geometry
 // B = R = 2), 1 = the same kernel with the clip switched off (A/B timing: it then stages the whole region like
 // round 3's kernel), 2 = round 3's brick kernel (brick_kernel.h; also what other brick geometries run on).
@@ -950,10 +950,9 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   if ((B + 2 * R) * (B + 2 * R) > kMaxRows) { B = 2; R = 2; }
   // x-long bricks (Bx = 2B, 3B, 4B: fewer, fuller groups but a longer region per query) were measured on workload M:
   // 0.638 / 0.698 / 0.768 ms against 0.633 ms for cubes (profiles/r02_nn_config_sweeps.txt)
-  int Bx = g_brick_Bx > 0 ? g_brick_Bx : B;
-  const bool clip = g_nn_kernel != 2 && B == 2 && R == 2 && Bx >= 2 && Bx <= 4;
-  if (!clip) Bx = B;   // round 3's kernel: cubes
-  const BrickParams b = make_bricks(g, B, Bx, R);
+  // x-long bricks (3, 4 cells): with the in-kernel clip 0.529 / 0.551 ms against 0.509 (profiles/r04_nn_experiments.txt)
+  const bool clip = g_nn_kernel != 2 && B == 2 && R == 2;   // other geometries run on round 3's kernel
+  const BrickParams b = make_bricks(g, B, B, R);
   PCD_TRY(sc->qsorted.reserve(Q));
   PCD_TRY(sc->ksorted.reserve(Q));
   // fallback list: one slot per query + the chunk slack of every wavefront of the brick kernel (brick_kernel.h)
@@ -1019,12 +1018,8 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(div_up(Q, G), 4) + 1, 256 * (uint64_t)g_brick_blocks_per_cu);
     if (clip) {
       const int fl = (g_collect_stats & ~2) | (g_nn_kernel == 1 ? 2 : 0);
-#define PCD_CLIP_LAUNCH(BX)                                                                                             \
-      hipLaunchKernelGGL(k_nn_brick_clip<BX>, dim3(blocks), dim3(256), 0, s, g, c->sorted.p, c->cell_start.p,             \
-                         sc->qsorted.p, sc->ksorted.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p,                \
-                         &sc->counters.p->fb_count, fl)
-      if (Bx == 2) PCD_CLIP_LAUNCH(2); else if (Bx == 3) PCD_CLIP_LAUNCH(3); else PCD_CLIP_LAUNCH(4);
-#undef PCD_CLIP_LAUNCH
+      hipLaunchKernelGGL(k_nn_brick_clip, dim3(blocks), dim3(256), 0, s, g, c->sorted.p, c->cell_start.p, sc->qsorted.p,
+                         sc->ksorted.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p, &sc->counters.p->fb_count, fl);
     } else
       hipLaunchKernelGGL(k_nn_brick<G>, dim3(blocks), dim3(256), 0, s, g, b, c->sorted.p, c->cell_start.p,
                          sc->qsorted.p, sc->ksorted.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p,
@@ -1212,13 +1207,6 @@ pcd_status pcd_nn_set_search(int kernel) {
   if (kernel < 0) return PCD_OK;
   PCD_REQUIRE(kernel <= 2, "kernel must be 0 (clipped brick kernel), 1 (the same, clip off) or 2 (round 3's brick kernel)");
   g_nn_kernel = kernel;
-  return PCD_OK;
-}
-
-/* brick length along x in cells (2..4) of the clipped brick kernel; 0 = the brick edge */
-pcd_status pcd_nn_set_brick_length(int cells) {
-  PCD_REQUIRE(cells == 0 || (cells >= 2 && cells <= 4), "brick length must be 0 (= the brick edge) or 2..4 cells");
-  g_brick_Bx = cells;
   return PCD_OK;
 }
 

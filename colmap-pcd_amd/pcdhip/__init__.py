@@ -606,11 +606,6 @@ def set_nn_search(kernel=0):
     _check(lib().pcd_nn_set_search(int(kernel)))
 
 
-def set_brick_length(cells=0):
-    """brick length along x in cells (2..4) of the clipped brick kernel; 0 = the brick edge"""
-    _check(lib().pcd_nn_set_brick_length(int(cells)))
-
-
 def set_nn_bookkeeping(radix_sort=0):
     _check(lib().pcd_nn_set_bookkeeping(int(radix_sort)))
 
