@@ -46,6 +46,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <atomic>
 #include <cfloat>
 
 #include "cloud.h"
@@ -920,13 +921,17 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
 // the hardware's workgroup dispatch as the load balancer (query costs spread 1:4).  2048 / 4096 / 16384 / 65536
 // workgroups: 0.384 / 0.387 / 0.368 / 0.369 ms at workload M, 0.136 / 0.125 / 0.126 / 0.125 ms on an eighth of it.
 constexpr unsigned g_fb_max_blocks = 16384;
-static int g_brick_B = 2, g_brick_R = 2, g_collect_stats = 0, g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
+// process-global tuning state (pcd_nn_set_*: experiments and tests, not part of the stable ABI): atomics, and every call
+// works on ONE snapshot taken at its top, so a setter racing a search on another thread cannot pair the slot bitmap of
+// one brick geometry with the kernel of another
+static std::atomic<int> g_brick_B{2}, g_brick_R{2}, g_collect_stats{0};
+constexpr int g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
 // first stage of the grid path: 0 = the clipped brick kernel (brick_clip_kernel.h; needs the default brick geometry
 // B = R = 2), 1 = the same kernel with the clip switched off (A/B timing: it then stages the whole region like
 // round 3's kernel), 2 = round 3's brick kernel (brick_kernel.h; also what other brick geometries run on).
-static int g_nn_kernel = 0;
+static std::atomic<int> g_nn_kernel{0};
 
-static int g_bk_sort = 0;   // 1: force the radix-sort bookkeeping (A/B timing, tests)
+static std::atomic<int> g_bk_sort{0};   // 1: force the radix-sort bookkeeping (A/B timing, tests)
 
 // slot table of the cloud for this brick geometry (built on first use, rebuilt when the geometry changes)
 static pcd_status brick_slots(pcd_cloud* c, QueryScratch* sc, const BrickParams& b, hipStream_t s) {
@@ -946,12 +951,14 @@ static pcd_status brick_slots(pcd_cloud* c, QueryScratch* sc, const BrickParams&
 template <int G>
 static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t* d_keys, hipStream_t s, bool refine) {
   const GridParams& g = c->grid;
-  int B = g_brick_B, R = g_brick_R;
+  // one snapshot of the tuning state for the whole call
+  const int nn_kernel = g_nn_kernel.load(), bk_sort = g_bk_sort.load(), collect_stats = g_collect_stats.load();
+  int B = g_brick_B.load(), R = g_brick_R.load();
   if ((B + 2 * R) * (B + 2 * R) > kMaxRows) { B = 2; R = 2; }
   // x-long bricks (Bx = 2B, 3B, 4B: fewer, fuller groups but a longer region per query) were measured on workload M:
   // 0.638 / 0.698 / 0.768 ms against 0.633 ms for cubes (profiles/r02_nn_config_sweeps.txt)
   // x-long bricks (3, 4 cells): with the in-kernel clip 0.529 / 0.551 ms against 0.509 (profiles/r04_nn_experiments.txt)
-  const bool clip = g_nn_kernel != 2 && B == 2 && R == 2;   // other geometries run on round 3's kernel
+  const bool clip = nn_kernel != 2 && B == 2 && R == 2;   // other geometries run on round 3's kernel
   const BrickParams b = make_bricks(g, B, B, R);
   PCD_TRY(sc->qsorted.reserve(Q));
   PCD_TRY(sc->ksorted.reserve(Q));
@@ -972,7 +979,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
   uint32_t shift = 8;
   while ((((uint64_t)b.nbricks + (1u << shift) - 1) >> shift) > 2304 && shift < 16) ++shift;
   const uint32_t ncoarse = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)b.nbricks + (1u << shift) - 1) >> shift));
-  if ((1u << shift) <= kBkMaxFine && ncoarse <= kBkMaxCoarse && g_bk_sort == 0) {
+  if ((1u << shift) <= kBkMaxFine && ncoarse <= kBkMaxCoarse && bk_sort == 0) {
     ScopedKernelTimer t("nn_brick_bookkeeping", s);
     if (!sc->bk_chist.p) {                 // histogram + cursors: zero once, k_bk_emit leaves them zero
       PCD_TRY(sc->bk_chist.reserve(4 * (size_t)kBkMaxCoarse + 4));
@@ -1017,13 +1024,13 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     ScopedKernelTimer t("nn_brick", s);
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(div_up(Q, G), 4) + 1, 256 * (uint64_t)g_brick_blocks_per_cu);
     if (clip) {
-      const int fl = (g_collect_stats & ~2) | (g_nn_kernel == 1 ? 2 : 0);
+      const int fl = (collect_stats & ~2) | (nn_kernel == 1 ? 2 : 0);
       hipLaunchKernelGGL(k_nn_brick_clip, dim3(blocks), dim3(256), 0, s, g, c->sorted.p, c->cell_start.p, sc->qsorted.p,
                          sc->ksorted.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p, &sc->counters.p->fb_count, fl);
     } else
       hipLaunchKernelGGL(k_nn_brick<G>, dim3(blocks), dim3(256), 0, s, g, b, c->sorted.p, c->cell_start.p,
                          sc->qsorted.p, sc->ksorted.p, sc->items.p, sc->counters.p, d_keys, sc->fb_list.p,
-                         &sc->counters.p->fb_count, g_collect_stats);
+                         &sc->counters.p->fb_count, collect_stats);
   }
   {
     ScopedKernelTimer t("nn_fallback", s);
@@ -1033,7 +1040,7 @@ static pcd_status run_grid(pcd_cloud* c, QueryScratch* sc, uint64_t Q, uint64_t*
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), g_fb_max_blocks);
     hipLaunchKernelGGL(k_nn_fallback<0>, dim3(blocks), dim3(256), 0, s, g, c->pyr, c->sorted.p, c->cell_start.p,
                        c->blk_aabb.p, sc->qf4.p, sc->fb_dense.p, &sc->counters.p->pad[0], 0u, d_keys,
-                       sc->counters.p, g_collect_stats, FbFused{nullptr, nullptr, 0, 0.0});
+                       sc->counters.p, collect_stats, FbFused{nullptr, nullptr, 0, 0.0});
   }
   return PCD_OK;
 }
@@ -1050,24 +1057,25 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
   QueryScratch* sc = scratch_of(c);
   if (Q == 0) return PCD_OK;
   PCD_REQUIRE(Q < 0xFFFFFFF0ull, "more than 2^32 queries in one call");
+  const int collect_stats = g_collect_stats.load();
   // Small batches (and PCD_NN_FALLBACK_ONLY): ONE launch -- k_nn_fallback converts the queries itself and writes
   // finalised keys, so the per-call latency is one kernel instead of prepare + memset + search + finalize.
   const bool one_launch = c->m > 0 && !refine &&
                           (algo == PCD_NN_FALLBACK_ONLY || (algo == PCD_NN_AUTO && Q <= kSmallBatch));
   if (one_launch) {
     PCD_TRY(sc->counters.reserve(1));
-    if (g_collect_stats) PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
+    if (collect_stats) PCD_HIP_TRY(hipMemsetAsync(sc->counters.p, 0, sizeof(NnCounters), s));
     ScopedKernelTimer t("nn_fallback", s);
     const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), g_fb_max_blocks);
     const FbFused fu{d_q, bound ? bound->d_max_range : nullptr, bound ? bound->count : 0, bound ? bound->fixed : 0.0};
     if (bound)
       hipLaunchKernelGGL(k_nn_fallback<2>, dim3(blocks), dim3(256), 0, s, c->grid, c->pyr, c->sorted.p, c->cell_start.p,
                          c->blk_aabb.p, (const float4*)nullptr, (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, (uint32_t)Q, d_keys, sc->counters.p, g_collect_stats, fu);
+                         (const uint32_t*)nullptr, (uint32_t)Q, d_keys, sc->counters.p, collect_stats, fu);
     else
       hipLaunchKernelGGL(k_nn_fallback<1>, dim3(blocks), dim3(256), 0, s, c->grid, c->pyr, c->sorted.p, c->cell_start.p,
                          c->blk_aabb.p, (const float4*)nullptr, (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, (uint32_t)Q, d_keys, sc->counters.p, g_collect_stats, fu);
+                         (const uint32_t*)nullptr, (uint32_t)Q, d_keys, sc->counters.p, collect_stats, fu);
     PCD_HIP_TRY(hipGetLastError());
     return PCD_OK;
   }
@@ -1102,7 +1110,7 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
       const unsigned blocks = (unsigned)std::min<uint64_t>(div_up(Q, 4), g_fb_max_blocks);
       hipLaunchKernelGGL(k_nn_fallback<0>, dim3(blocks), dim3(256), 0, s, c->grid, c->pyr, c->sorted.p, c->cell_start.p,
                          c->blk_aabb.p, sc->qf4.p, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)Q,
-                         d_keys, sc->counters.p, g_collect_stats, FbFused{nullptr, nullptr, 0, 0.0});
+                         d_keys, sc->counters.p, collect_stats, FbFused{nullptr, nullptr, 0, 0.0});
     } else if (algo == PCD_NN_AUTO || algo == PCD_NN_GRID) {
       PCD_TRY(run_grid<8>(c, sc, Q, d_keys, s, refine || bound != nullptr));   // incoming keys matter: carry them
     } else {
@@ -1195,7 +1203,8 @@ pcd_status pcd_nn_last_stats(pcd_cloud* c, pcd_nn_stats* st) {
   st->fallback_queries = h.fallback_queries;
   st->fallback_points = h.fallback_points;
   st->pair_evals = h.pair_evals;
-  if (std::getenv("PCD_FB_STATS"))
+  static const bool print_walks = std::getenv("PCD_FB_STATS") != nullptr;   // read once per process
+  if (print_walks)
     std::fprintf(stderr, "[pcd] fallback walk: %llu queries, %.1f steps / %.1f leaf scans per query, max %u / %u\n",
                  (unsigned long long)h.fallback_queries, h.fallback_queries ? (double)h.fb_steps / h.fallback_queries : 0.0,
                  h.fallback_queries ? (double)h.fb_leaves / h.fallback_queries : 0.0, h.fb_max_steps, h.fb_max_leaves);

@@ -20,6 +20,7 @@
 // k_sift_finalize merges the partials in ascending order (ties -> first index, as the reference's ascending strict->
 // scan), applies acos / max_distance / max_ratio; the cross check and the ordered compaction follow.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -32,6 +33,11 @@ namespace pcd {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+
+// test / fuzzing knobs (pcd_sift_set_tuning; 0 = the library's choice): column chunks per stripe walk, bytes of partial
+// results per sub-batch.  Atomics read once per call: no environment lookups on the call path.
+static std::atomic<int> g_sift_nchunk{0};
+static std::atomic<uint64_t> g_sift_batch_partials{0};
 
 constexpr int kSiftTile = 128;
 constexpr int kSiftPitch = 144;   // bytes per staged descriptor row (128 + 16 pad)
@@ -517,9 +523,8 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
   const int nby = (n1 + kSiftTile - 1) / kSiftTile, nbx = (n2 + kSiftTile - 1) / kSiftTile;
   // stripe walk: enough (row tile, chunk) workgroups to fill the chip twice over
   // (a chunk is at most 128 column tiles: the stripe kernel's 8-bit sequence code)
-  // PCD_SIFT_NCHUNK (tests / fuzzing): force the number of column chunks, e.g. 1 = every stripe walks all tiles
-  const char* nce = std::getenv("PCD_SIFT_NCHUNK");   // read per call: tests switch it inside one process
-  const int nchunk_env = nce ? std::atoi(nce) : 0;
+  // pcd_sift_set_tuning (tests / fuzzing) can force the number of column chunks, e.g. 1 = every stripe walks all tiles
+  const int nchunk_env = g_sift_nchunk.load(std::memory_order_relaxed);   // pcd_sift_set_tuning (tests / fuzzing)
   const int want = nchunk_env > 0 ? std::min(nchunk_env, nbx) : std::min(nbx, (512 + nby - 1) / nby);
   const int nchunk = std::max({1, want, (nbx + 127) / 128});
   const int ct_per_chunk = (nbx + nchunk - 1) / nchunk;
@@ -573,8 +578,8 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
                                     SiftScratch& sc, hipStream_t s) {
   const uint64_t total_rows = first_row[n_images];
   PCD_REQUIRE(total_rows < (1ull << 32), "arena larger than 2^32 descriptors");
-  const char* budget_env = std::getenv("PCD_SIFT_BATCH_PARTIALS");
-  const size_t budget = budget_env ? (size_t)std::strtoull(budget_env, nullptr, 10) : kSiftBatchPartials;
+  const uint64_t budget_set = g_sift_batch_partials.load(std::memory_order_relaxed);   // pcd_sift_set_tuning
+  const size_t budget = budget_set ? (size_t)budget_set : kSiftBatchPartials;
   for (int i = 0; i < n_images; ++i) PCD_REQUIRE(first_row[i] <= first_row[i + 1], "first_row must ascend");
   uint64_t max_nbx = 1;
   bool wide = false;   // a set too long for the one-workgroup compaction: those batches run pair by pair
@@ -619,8 +624,7 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
       const int nby0 = std::max<int>(1, (int)((first_row[a0 + 1] - first_row[a0] + kSiftTile - 1) / kSiftTile));
       const int nbx0 = std::max<int>(1, (int)((first_row[b0 + 1] - first_row[b0] + kSiftTile - 1) / kSiftTile));
       const long left = n_pairs - p0;
-      const char* nce = std::getenv("PCD_SIFT_NCHUNK");
-      const int nchunk_env = nce ? std::atoi(nce) : 0;
+      const int nchunk_env = g_sift_nchunk.load(std::memory_order_relaxed);
       const long want = nchunk_env > 0 ? std::min<long>(nchunk_env, nbx0) : std::min<long>(nbx0, (512 + nby0 * left - 1) / (nby0 * left));
       const int nchunk = (int)std::max<long>({1, want, (long)((max_nbx + 127) / 128)});   // a chunk is at most 128 column tiles
       size_t o12 = 0, o21 = 0, om12 = 0, om21 = 0;
@@ -687,6 +691,15 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
 using namespace pcd;
 
 extern "C" {
+
+/* tuning hook (tests, fuzzing; not part of the stable ABI): force the number of column chunks of a stripe walk and the
+ * bytes of partial results per sub-batch of pcd_sift_match_batch; 0 = the library's choice */
+pcd_status pcd_sift_set_tuning(int nchunk, uint64_t batch_partials_bytes) {
+  PCD_REQUIRE(nchunk >= 0, "nchunk");
+  g_sift_nchunk.store(nchunk, std::memory_order_relaxed);
+  g_sift_batch_partials.store(batch_partials_bytes, std::memory_order_relaxed);
+  return PCD_OK;
+}
 
 pcd_status pcd_sift_match_device(int device, const uint8_t* d_desc1, int n1, const uint8_t* d_desc2, int n2,
                                  float max_ratio, float max_distance, int cross_check, int32_t* d_m12,

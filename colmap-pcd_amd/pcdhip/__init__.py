@@ -606,6 +606,13 @@ def set_nn_search(kernel=0):
     _check(lib().pcd_nn_set_search(int(kernel)))
 
 
+def set_sift_tuning(nchunk=0, batch_partials=0):
+    """tests / fuzzing: column chunks per stripe walk and bytes of partial results per sub-batch (0 = library's choice)"""
+    L = lib()
+    L.pcd_sift_set_tuning.argtypes = [C.c_int, C.c_uint64]
+    _check(L.pcd_sift_set_tuning(int(nchunk), int(batch_partials)))
+
+
 def set_nn_bookkeeping(radix_sort=0):
     _check(lib().pcd_nn_set_bookkeeping(int(radix_sort)))
 

@@ -110,6 +110,11 @@ pcd_status pcd_cloud_download(const pcd_cloud* c, float* xyz /*[size][3]*/, floa
  * shards, one per device; indices everywhere are the post-filter row indices
  * of the WHOLE cloud, and every result equals the single-device one bit for
  * bit (ties -> lowest index, also across shards).
+ * Verification status: every test so far has run on hosts with ONE GPU, all
+ * shards on device 0.  The code paths that only exist between distinct
+ * devices (peer copies of the built-in reduction, per-device streams) are
+ * covered by tests/test_sharded_gpu.py::test_shards_on_distinct_devices,
+ * which skips itself below two devices -- they have not executed yet.
  * --------------------------------------------------------------------- */
 typedef struct pcd_cloud_shards pcd_cloud_shards;
 pcd_status pcd_cloud_create_sharded(const float* xyz, const float* nrm, uint64_t n, const pcd_cloud_options* opts,

@@ -10,6 +10,9 @@ import pcdhip
 from oracle import pyoracle as oracle
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+# FUZZ_SIFT_NCHUNK / FUZZ_SIFT_BATCH_PARTIALS: pcd_sift_set_tuning for the whole sweep (chunks per stripe walk, bytes of
+# partial results per sub-batch)
+pcdhip.set_sift_tuning(int(os.environ.get("FUZZ_SIFT_NCHUNK", "0")), int(os.environ.get("FUZZ_SIFT_BATCH_PARTIALS", "0")))
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 

@@ -199,11 +199,13 @@ def _pose_tangent_gradient(s, out, res):
     return g
 
 
-@pytest.mark.parametrize("cams,points,shard", [(450, 400_000, None), (5000, 2_000_000, 8)],
-                         ids=["config B: 450 cams / 400k pts / ~2M obs", "config C: one rank's share of 5000 cams / 2M tracks"])
+@pytest.mark.parametrize("cams,points,shard", [(450, 400_000, None), (5000, 2_000_000, 8), (5000, 2_000_000, None)],
+                         ids=["config B: 450 cams / 400k pts / ~2M obs", "config C: one rank's share of 5000 cams / 2M tracks",
+                              "config C at full size on one GPU: 5000 cams / 2M tracks / ~9.5M obs"])
 def test_config_size_properties(gpu, oracle, cams, points, shard):
-    """BASELINE.json's BA sizes -- B (Smith Hall 450: 450 cameras / 400 k points / ~2 M observations / ~350 k LiDAR terms)
-    and one rank's eighth of C (5 000 cameras / 2 M tracks / ~10 M observations, sharded by track as bench.py does) --
+    """BASELINE.json's BA sizes -- B (Smith Hall 450: 450 cameras / 400 k points / ~2 M observations / ~350 k LiDAR terms),
+    one rank's eighth of C (5 000 cameras / 2 M tracks / ~10 M observations, sharded by track as bench.py does) and C
+    whole on one GPU (it fits: 2.9 ms per step, profiles/r03_bench_config_C_single_gpu.json) --
     checked through properties that do not depend on the size: cost = 1/2 |r|^2 of the returned residuals, point and
     pose gradients = J^T r re-assembled on the host from the returned raw blocks, W = Jp^T JX on a sample, and the
     oracle's Jet residuals / Jacobians on a track sample."""

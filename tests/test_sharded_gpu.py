@@ -109,3 +109,55 @@ def test_caller_supplied_reduction_and_raw_frame(gpu, oracle):
         if k in b:
             assert np.array_equal(np.asarray(a[k]).view(np.uint8), np.asarray(b[k]).view(np.uint8)), k
     single.close(); sh.close()
+
+
+@pytest.mark.parametrize("callback", [False, True], ids=["library peer-copy reduction", "caller-supplied reduction"])
+def test_shards_on_distinct_devices(gpu, oracle, callback):
+    """The cross-device paths of csrc/shards.hip -- hipMemcpyPeer between DISTINCT devices in the library's reduction, the
+    per-device null streams and hipSetDevice switching of the search, callbacks that receive buffers living on different
+    devices -- need a host with more than one GPU.  The boxes this repository's GPU tests have run on so far have one:
+    only the same-device configuration above has ever executed (include/pcdhip.h says so)."""
+    ndev = gpu.device_count()
+    if ndev < 2:
+        pytest.skip(f"{ndev} gfx950 device visible: the distinct-device configuration needs at least 2")
+    devices = list(range(min(ndev, 4)))
+    xyz, nrm, src = _cloud_with_straddling_ties()
+    q = synth.queries(xyz, 8000, seed=5)
+    q[:400] = xyz[src].astype(np.float64)
+    q[400:420] = np.nan
+    ref_cloud = gpu.Cloud(xyz, nrm, raw_lidar_frame=False)
+    ref = ref_cloud.nn(q)
+    red = None
+    if callback:
+        def view(ptr, count, dtype, dev):
+            class _A:   # noqa: N801
+                pass
+            a = _A()
+            a.__cuda_array_interface__ = {"shape": (count,), "typestr": dtype, "data": (ptr, False), "version": 2}
+            return torch.as_tensor(a, device=f"cuda:{dev}")
+
+        def reduce_with(op):
+            def fn(user, bufs, devs, n, count, dtype):
+                ts = [view(bufs[s], count, dtype, devs[s]) for s in range(n)]
+                for t, d in zip(ts, [devs[s] for s in range(n)]):
+                    torch.cuda.synchronize(d)
+                m = ts[0].clone()
+                for t in ts[1:]:
+                    m = op(m, t.to(m.device))
+                for t in ts:
+                    t.copy_(m.to(t.device))
+                for s in range(n):
+                    torch.cuda.synchronize(devs[s])
+                return 0
+            return fn
+        mn, sm = reduce_with(torch.minimum), reduce_with(torch.add)
+        red = gpu.ShardReduce(gpu.ShardReduce.MINFN(lambda u, b, d, n, c: mn(u, b, d, n, c, "<i8")),
+                              gpu.ShardReduce.SUMFN(lambda u, b, d, n, c: sm(u, b, d, n, c, "<i4")), None)
+    sh = gpu.ShardedCloud(xyz, nrm, devices, raw_lidar_frame=False)
+    _exact(sh.nn(q, red) if red else sh.nn(q), ref, f"shards on devices {devices}")
+    mr = synth.max_range_schedule(len(q), seed=2)
+    a = ref_cloud.associate(q, mr, gpu.GATE_MAPPER_LOCAL)
+    b = sh.associate(q, mr, gpu.GATE_MAPPER_LOCAL, red) if red else sh.associate(q, mr, gpu.GATE_MAPPER_LOCAL)
+    for k in ("type", "nn_idx", "nn_sqdist", "lidar_xyz", "abcd", "dist", "angle", "dist2plane"):
+        assert np.array_equal(np.ascontiguousarray(a[k]).view(np.uint8), np.ascontiguousarray(b[k]).view(np.uint8)), k
+    ref_cloud.close(); sh.close()

@@ -12,6 +12,15 @@ from tests.test_sift_cpu import sift_reference_cases
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def sift_tuning(gpu):
+    """pcd_sift_set_tuning for one test (chunks per stripe walk, bytes of partials per sub-batch), reset afterwards"""
+    def set_(nchunk=0, batch_partials=0):
+        gpu.set_sift_tuning(nchunk, batch_partials)
+    yield set_
+    gpu.set_sift_tuning(0, 0)
+
+
 def test_reference_known_answers_on_gpu(gpu, oracle):
     """expected counts of src/feature/sift_test.cc:296-428: 2, 0, 0, 0, 50, 50, 48, 49, 50, 48"""
     for name, d1, d2, opt, expected in sift_reference_cases(oracle):
@@ -44,11 +53,11 @@ def test_random_descriptors_exact(gpu, oracle, n1, n2, cross):
 
 
 @pytest.mark.parametrize("nchunk", [1, 2, 5])
-def test_long_walks_with_ties(gpu, oracle, nchunk, monkeypatch):
-    """the stripe kernel's running row-direction state over MANY column tiles (PCD_SIFT_NCHUNK forces the number of
+def test_long_walks_with_ties(gpu, oracle, nchunk, sift_tuning):
+    """the stripe kernel's running row-direction state over MANY column tiles (pcd_sift_set_tuning forces the number of
     column chunks; the default picks one tile per chunk at these sizes): few distinct descriptors => equal best
     scores in different tiles, blocks, lanes and chunks, so every tie rule of the end-of-walk merge decides"""
-    monkeypatch.setenv("PCD_SIFT_NCHUNK", str(nchunk))
+    sift_tuning(nchunk=nchunk)
     rng = np.random.default_rng(100 + nchunk)
     n1, n2 = 700, 1900                                   # 6 row tiles x 15 column tiles
     base = rng.integers(0, 90, (6, 128), dtype=np.uint8)
@@ -120,13 +129,13 @@ def _sift_like_images(rng, sizes):
 
 
 @pytest.mark.parametrize("cross,budget", [(True, None), (False, None), (True, "20000")])
-def test_batch_equals_pair_by_pair_and_oracle(gpu, oracle, cross, budget, monkeypatch):
+def test_batch_equals_pair_by_pair_and_oracle(gpu, oracle, cross, budget, sift_tuning):
     """pcd_sift_match_batch (SiftFeatureMatcher::Match(image_pairs), feature/matching.cc:798) over a ragged set of
     images incl. an empty one, a 1-descriptor one, sizes that are not tile multiples, a pair of an image with
     itself and repeated pairs: every list equals the single-pair entry and the oracle.  budget = a small bound on
     the partial-result scratch, so the pair list is cut into many sub-batches (launch sets)."""
     if budget:
-        monkeypatch.setenv("PCD_SIFT_BATCH_PARTIALS", budget)
+        sift_tuning(batch_partials=int(budget))
     rng = np.random.default_rng(11)
     sizes = [300, 0, 1, 129, 700, 128, 515]
     imgs = _sift_like_images(rng, sizes)
