@@ -16,7 +16,7 @@ outl = float(sys.argv[6]) if len(sys.argv) > 6 else 0.05
 kern = int(os.environ.get("PCD_PROBE_KERNEL", "0"))   # pcd_nn_set_search: 0 clipped brick kernel, 1 clip off, 2 round 3's kernel
 pcdhip.set_nn_search(kern)
 print("first-stage kernel", kern, flush=True)
-t = time.time(); xyz, nrm = synth.cloud_planes(N); q = synth.queries(xyz, Q, outlier_frac=outl); print("gen %.1fs" % (time.time() - t), flush=True)
+t = time.time(); xyz, nrm = synth.cloud_planes(N); q = synth.queries(xyz, Q, outlier_frac=outl, sigma=float(os.environ.get("PCD_PROBE_SIGMA", "0.25"))); print("gen %.1fs" % (time.time() - t), flush=True)
 t = time.time(); c = pcdhip.Cloud(xyz, nrm, raw_lidar_frame=False, cell_size=cell); print("build %.2fs" % (time.time() - t), c.info(), flush=True)
 dq = torch.from_numpy(q).cuda(); keys = torch.empty(Q, dtype=torch.int64, device="cuda")
 pcdhip.set_nn_tuning(B, R, 1)
