@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_brick_clip(GridParams g, const fl
       const int c1[3] = {min(2 * bx + 4, g.dims[0]), min(2 * by + 4, g.dims[1]), min(2 * bz + 4, g.dims[2])};
       const float bound = (flags & kAblateBound) ? 3e38f : proven_bound_f(g, m0.q.x, m0.q.y, m0.q.z, c0, c1);
       unproven = !(__uint_as_float((uint32_t)(mine >> 32)) < bound) && !(flags & kAblateFallback);
-      keys[my_qi] = mine;
+      keys[my_qi] = unproven ? mine : finalized_key(mine);   // final, or the starting bound of the exact fallback
     }
     const unsigned long long um = __ballot(unproven);
     if (um) {   // chunked fallback list: brick_kernel.h

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, PCD_BRICK_MINWAVES) void k_nn_brick(GridParams
       const double bound = proven_bound(g, m0.q.x, m0.q.y, m0.q.z, c0, c1);
       const double bd = (double)__uint_as_float((uint32_t)(mine >> 32));
       unproven = !(bd < bound) && !(flags & kAblateFallback);
-      keys[my_qi] = mine;  // final, or the starting bound of the fallback
+      keys[my_qi] = unproven ? mine : finalized_key(mine);  // final, or the starting bound of the fallback
     }
     const unsigned long long um = __ballot(unproven);
     if (um) {

@@ -85,6 +85,13 @@ static BrickParams make_bricks(const GridParams& g, int B, int Bx, int R) {
   return b;
 }
 
+// keys still at their initial value (kKeyInit, or a bound with the impossible index) mean "nothing found".  Every
+// kernel that writes a FINAL key writes it in this form (the brick kernels for the queries they prove, the pyramid walk
+// for all of its queries, the prepare kernels for the queries no search kernel touches): no separate pass over the keys.
+__device__ __forceinline__ uint64_t finalized_key(uint64_t k) {
+  return (k == kKeyInit || (uint32_t)k == 0xFFFFFFFFu) ? PCD_KEY_NONE : k;
+}
+
 // ------------------------------------------------------- query preparation --
 // ply.cc:92: feature_point.getVector3fMap() = point_3d.cast<float>()
 __global__ void k_prepare_queries(const double* __restrict__ q, uint64_t Q, float4* __restrict__ qf4,
@@ -94,7 +101,7 @@ __global__ void k_prepare_queries(const double* __restrict__ q, uint64_t Q, floa
   float x = (float)q[3 * i], y = (float)q[3 * i + 1], z = (float)q[3 * i + 2];
   bool ok = isfinite(x) && isfinite(y) && isfinite(z);
   qf4[i] = make_float4(x, y, z, ok ? 1.f : 0.f);
-  keys[i] = kKeyInit;
+  keys[i] = ok ? kKeyInit : PCD_KEY_NONE;   // a query no search kernel touches leaves with its final key
 }
 
 // pcd_nn_refine_device: the keys come in with another shard's results.  A query stays active only if this shard
@@ -115,7 +122,7 @@ __global__ void k_prepare_refine(const double* __restrict__ q, uint64_t Q, const
     ok = l2_simple3(x, y, z, px, py, pz) <= __uint_as_float((uint32_t)(k >> 32));
   }
   qf4[i] = make_float4(x, y, z, ok ? 1.f : 0.f);
-  keys[i] = k;
+  keys[i] = ok ? k : finalized_key(k);   // inactive: the key it came with, in its final form
 }
 
 // Gate-bounded search (the association entry points): the three call sites reject an association whose point-to-point
@@ -143,10 +150,6 @@ __device__ __forceinline__ uint64_t bounded_init_key(double R, double x, double 
   }
   return k;
 }
-// keys still at their initial value (kKeyInit, or a bound with the impossible index) mean "nothing found"
-__device__ __forceinline__ uint64_t finalized_key(uint64_t k) {
-  return (k == kKeyInit || (uint32_t)k == 0xFFFFFFFFu) ? PCD_KEY_NONE : k;
-}
 __global__ void k_prepare_bounded(const double* __restrict__ q, uint64_t Q, const double* __restrict__ max_range,
                                   uint64_t mr_count, double fixed_range, float4* __restrict__ qf4,
                                   uint64_t* __restrict__ keys) {
@@ -155,7 +158,8 @@ __global__ void k_prepare_bounded(const double* __restrict__ q, uint64_t Q, cons
   float x = (float)q[3 * i], y = (float)q[3 * i + 1], z = (float)q[3 * i + 2];
   bool ok = isfinite(x) && isfinite(y) && isfinite(z);
   qf4[i] = make_float4(x, y, z, ok ? 1.f : 0.f);
-  keys[i] = bounded_init_key(max_range ? max_range[mr_count == 1 ? 0 : i] : fixed_range, q[3 * i], q[3 * i + 1], q[3 * i + 2]);
+  keys[i] = ok ? bounded_init_key(max_range ? max_range[mr_count == 1 ? 0 : i] : fixed_range, q[3 * i], q[3 * i + 1], q[3 * i + 2])
+               : PCD_KEY_NONE;
 }
 
 __global__ void k_finalize_keys(uint64_t* __restrict__ keys, uint64_t Q) {
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(256) void k_nn_fallback(GridParams g, PyramidParams
       }
     }
 #undef PCD_FB_EXPAND
-    if (lane == 0) keys[qi] = FUSED ? finalized_key(best) : best;
+    if (lane == 0) keys[qi] = finalized_key(best);   // the walk is exact: whatever it ends with is final
     st_q += 1;
     st_steps += q_steps; st_leaves += q_leaves;
     st_max_steps = q_steps > st_max_steps ? q_steps : st_max_steps;
@@ -1118,7 +1122,7 @@ static pcd_status nn_device(pcd_cloud* c, const double* d_q, uint64_t Q, int alg
       return PCD_ERR_INVALID;
     }
   }
-  {
+  if (c->m == 0 || algo == PCD_NN_BRUTEFORCE) {   // raw keys left behind: the brute-force kernel's atomicMin, an empty cloud
     ScopedKernelTimer t("nn_finalize", s);
     hipLaunchKernelGGL(k_finalize_keys, dim3(div_up(Q, 256)), dim3(256), 0, s, d_keys, Q);
   }
