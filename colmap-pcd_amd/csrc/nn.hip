@@ -929,7 +929,11 @@ constexpr unsigned g_fb_max_blocks = 16384;
 // works on ONE snapshot taken at its top, so a setter racing a search on another thread cannot pair the slot bitmap of
 // one brick geometry with the kernel of another
 static std::atomic<int> g_brick_B{2}, g_brick_R{2}, g_collect_stats{0};
+#ifdef PCD_ABLATE   // occupancy experiments (tools/nn_ablate.py): workgroups of the brick kernels per CU
+static const int g_brick_blocks_per_cu = std::getenv("PCD_BRICK_BLOCKS") ? std::atoi(std::getenv("PCD_BRICK_BLOCKS")) : PCD_BRICK_MINWAVES;
+#else
 constexpr int g_brick_blocks_per_cu = PCD_BRICK_MINWAVES;
+#endif
 // first stage of the grid path: 0 = the clipped brick kernel (brick_clip_kernel.h; needs the default brick geometry
 // B = R = 2), 1 = the same kernel with the clip switched off (A/B timing: it then stages the whole region like
 // round 3's kernel), 2 = round 3's brick kernel (brick_kernel.h; also what other brick geometries run on).

@@ -1,4 +1,5 @@
-"""timing-only ablations of k_nn_brick (results are wrong while a flag is set).  Needs a variant of the library
+"""timing-only ablations of k_nn_brick_clip (results are wrong while a flag is set; PCD_BRICK_BLOCKS=1..4 in the
+environment = workgroups per CU, i.e. wavefronts per SIMD, of the brick kernel).  Needs a variant of the library
 built with -DPCD_ABLATE (the shipped one has no ablation branches):
   PCDHIP_LIB=colmap-pcd_amd/variants/libpcdhip_ablate.so python tools/nn_ablate.py"""
 import os
