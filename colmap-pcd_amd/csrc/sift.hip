@@ -40,29 +40,60 @@ static std::atomic<int> g_sift_nchunk{0};
 static std::atomic<uint64_t> g_sift_batch_partials{0};
 
 constexpr int kSiftTile = 128;
-constexpr int kSiftPitch = 144;   // bytes per staged descriptor row (128 + 16 pad)
 constexpr int kSiftConst = 128 * 128 * 128;
 #ifndef PCD_SIFT_WGS
 #define PCD_SIFT_WGS 2
 #endif
+#ifndef PCD_SIFT_ABLATE   // timing-only variants (tools/sift_ablate.sh; results are wrong): 1 no scan, 2 no slow path,
+#define PCD_SIFT_ABLATE 0 // 4 no fetch / store of further tiles, 8 no barrier, 16 no MFMA
+#endif
 
-__global__ void k_sift_rowsum(const uint8_t* __restrict__ da, int na, int* __restrict__ suma,
-                              const uint8_t* __restrict__ db, int nb, int* __restrict__ sumb) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= na + nb) return;
-  const uint8_t* d = i < na ? da : db;
-  int* sum = i < na ? suma : sumb;
-  if (i >= na) i -= na;
-  const uint4* p = reinterpret_cast<const uint4*>(d + (size_t)i * 128);
+// ---- preparation: the re-centred, padded copy the walks read ------------------------------------------------------
+// Every image (descriptor set) is copied ONCE per call into scratch with its bytes re-centred (x ^ 0x80) and its rows
+// padded with zero descriptors to a multiple of 128, next to one constant per row: cc = 128 sum(row) - 128^3 (a padding
+// row: -128^3, i.e. true score 0 against anything).  The walks then stage column tiles with LDS-DMA (no registers, no
+// VALU, no bounds tests) and read their row fragments unconditionally.
+struct SiftImageDev {
+  const uint8_t* src;   // the image's descriptors (n x 128 bytes)
+  uint32_t n;           // descriptors
+  uint32_t prow;        // first row of the image in the padded copy (a multiple of 128)
+};
+
+// one workgroup per 128-row tile: thread (row = tid >> 1, half = tid & 1) moves 64 bytes
+__device__ __forceinline__ void sift_prep_tile(const SiftImageDev im, int tile, uint8_t* __restrict__ xa,
+                                               int* __restrict__ cc) {
+  const uint32_t row = (uint32_t)tile * kSiftTile + (threadIdx.x >> 1), h = threadIdx.x & 1;
+  if ((uint32_t)tile * kSiftTile >= im.n) return;   // (the grid is sized for the largest image; an empty one has no tiles)
+  uint4 v[4];
   unsigned s = 0;
+  if (row < im.n) {
+    const uint4* p = reinterpret_cast<const uint4*>(im.src + (size_t)row * 128 + h * 64);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const uint4 v = p[c];
-    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    for (int c = 0; c < 4; ++c) {
+      v[c] = p[c];
+      const unsigned w[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s += (w[k] & 0xFF) + ((w[k] >> 8) & 0xFF) + ((w[k] >> 16) & 0xFF) + (w[k] >> 24);
+      for (int k = 0; k < 4; ++k) s += (w[k] & 0xFF) + ((w[k] >> 8) & 0xFF) + ((w[k] >> 16) & 0xFF) + (w[k] >> 24);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = make_uint4(0, 0, 0, 0);
   }
-  sum[i] = (int)s;
+  s += __shfl_xor(s, 1);
+  uint4* q = reinterpret_cast<uint4*>(xa + (size_t)(im.prow + row) * 128 + h * 64);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    q[c] = make_uint4(v[c].x ^ 0x80808080u, v[c].y ^ 0x80808080u, v[c].z ^ 0x80808080u, v[c].w ^ 0x80808080u);
+  if (h == 0) cc[im.prow + row] = 128 * (int)s - kSiftConst;
+}
+
+__global__ __launch_bounds__(256) void k_sift_prep_pair(SiftImageDev a, SiftImageDev b, uint8_t* __restrict__ xa,
+                                                        int* __restrict__ cc) {
+  sift_prep_tile(blockIdx.y == 0 ? a : b, blockIdx.x, xa, cc);
+}
+__global__ __launch_bounds__(256) void k_sift_prep_images(const SiftImageDev* __restrict__ images,
+                                                          uint8_t* __restrict__ xa, int* __restrict__ cc) {
+  sift_prep_tile(images[blockIdx.y], blockIdx.x, xa, cc);
 }
 
 // running (best, second, argbest) with the reference's update rule: strictly greater replaces the best
@@ -81,260 +112,317 @@ __device__ __forceinline__ void top2_merge(int b2, int s2, int a2, int& best, in
   second = nsecond;
 }
 
-// ---- persistent row-stripe variant (round 3: ONE orientation) ----------------------------------------------------
-// Workgroup (by, chunk) owns the 128-row tile `by` of set 1 and walks `ct` column tiles of set 2 (staged through LDS,
-// the next tile fetched into registers while the current one is used; one __syncthreads per tile).  A wavefront owns
-// 64 rows (wr) x the 64-column half wc of every tile and works in blocks of 64 x 32: 8 MFMAs into one of TWO
-// accumulator sets while the other set -- the previous block -- is scanned, so the matrix pipe and the VALU run side
-// by side inside one wavefront (rounds 1-2 computed every tile in both orientations to keep both scans register-local
-// and the two phases of the workgroup's wavefronts ran in step: MFMA time + scan time, 0.13 of the dense i8 peak).
-//   * the set-1 fragments of the wavefront's 64 rows stay in registers for the whole walk (32 VGPRs);
-//   * accumulators are preloaded with the ROW constant 128 rowsum1 (LDS, in C-layout order: no VALU);
-//   * column direction (best set-1 row per set-2 column): register-local in the C layout (lane = column); packed
-//     value = (acc << 8) + code, code = 64 - row (an inline constant per register), 3 VALU per score; one partial
-//     per (64-row half, column) and block, as before;
-//   * row direction (best set-2 column per set-1 row): every lane keeps a running (best, second) for each of its 32
-//     (row, lane-column-class) slots over the WHOLE walk; packed value = (acc << 8) + K, K = (column constant << 8) +
-//     (255 - block sequence number) is one VGPR per block, so the column constant costs nothing: 3 VALU per score.
-//     The 32 lanes that share a row are merged ONCE at the end of the walk, through LDS.
-// part12 [nchunk][n1] int4 {best, second, arg, 0}; part21 [2 nby][n2] int2 = the packed (best, second) of the column
-// scan, relative to the column constant (sift_finalize decodes: 8 bytes per partial instead of 16 -- the finalize
-// kernel is bound by reading them).  A chunk is at most 128 tiles (8-bit sequence code).
-__device__ __forceinline__ void sift_stripe(const uint8_t* __restrict__ d1, int n1, const uint8_t* __restrict__ d2,
-                                            int n2, const int* __restrict__ sum1, const int* __restrict__ sum2,
-                                            int4* __restrict__ part12, int2* __restrict__ part21, int nbx,
-                                            int ct_per_chunk, const int chunk, const int by) {
-  __shared__ __attribute__((aligned(16))) uint8_t sB[2][kSiftTile * kSiftPitch];
-  __shared__ int sSumB[2][kSiftTile];
-  __shared__ __attribute__((aligned(16))) int sRc[2][2][32];   // [wr][lane half][mt * 16 + reg]: 128 rowsum1 in C-layout order
-  __shared__ int4 sMerge[2][64];
-  const int row0 = by * kSiftTile;
+// ---- persistent row-stripe walk, ONE direction per walk, lane = row (round 4) -------------------------------------
+// Workgroup (by, chunk) owns the 512-row stripe `by` of the ROW set and walks `ct` 128-descriptor tiles of the COLUMN
+// set.  Tiles are staged with LDS-DMA from the prepared copy (k_sift_prep_*), double-buffered, one barrier per tile; a
+// wavefront owns 128 rows and every 32-column block of a tile: 16 MFMAs per block, in two halves of 2 row tiles x 4
+// k-steps into TWO accumulator sets -- one half is multiplied while the other is scanned.
+//
+// The product is taken TRANSPOSED, D = B A^T (the staged column fragment is the MFMA's first operand), so that in the
+// result layout a LANE is a ROW of the row set (lane & 31; the two lane halves hold columns 4 apart) and a REGISTER is a
+// column of the block.  The row's running (best, second, argbest) is then three registers per lane and row tile that live
+// for the whole walk, and a register of scores concerns them only if SOME lane's score beats its row's running second
+// best: one v_cmp (eight issued back to back into SGPR pairs) + one scalar test per 64 scores, the fast path the
+// fall-through.  With k columns seen the chance that a given row's pair changes is 2 / k, so after the first tiles almost
+// every register takes the fast path.  Round 3 kept both directions' top-2 up to date for every score of ONE product
+// (6 half-rate VALU per score against 8 MFMAs per 64 x 32 block: 0.17 of the dense i8 peak, bound by the scan); here the
+// other direction (best row per column) is the same walk with the two sets exchanged: every tile is multiplied twice,
+// as in rounds 1-2, but nothing else is done twice and a walk costs little more than its MFMAs.
+//   * 512 rows per stripe: a staged tile (16 KB) feeds 256 MFMAs -- at 128 rows per stripe the walks of one 50-image
+//     block pulled 157 GB through L2 (6 TB/s at the speed reached: the bound); LDS reads per block: 4 KB of column
+//     fragments + 4 KB of constants for 16 MFMAs;
+//   * the row set's fragments of the wavefront's 128 rows stay in registers for the whole walk (64 VGPRs);
+//   * the first MFMA of a chain takes the COLUMN constants 128 sum(col) - 128^3 as its C operand (16 registers read from
+//     LDS once per block, 4 consecutive columns per 16-byte read: no VALU); the row constant 128 sum(row) is one register
+//     per lane and row tile and never added inside the walk -- the running values are kept relative to it;
+//   * the staged tile is swizzled (16-byte chunk q of row r at position q ^ (r & 7): the DMA's lane -> source mapping
+//     does it) so that the fragment reads of 32 rows at one k-chunk spread over all banks;
+//   * the slow path (some lane beats its second best) is six VALU on the whole register, harmless for the lanes that do
+//     not: arg <- (v > best ? code : arg), second <- med3(best, second, v), best <- max(best, v); code = 16 x column
+//     block sequence number + register, wave-uniform; the column index is decoded once at the end of the walk.  The
+//     masks of later registers of a group of eight are taken against the second best as it was before the earlier ones
+//     were absorbed: a superset of the lanes that still beat it;
+//   * strict "greater" in ascending column order inside a lane = the reference's rule (sift.cc:72-83: the first of equal
+//     scores keeps the best place); the lane halves and the chunks are merged with top2_merge (equal best: lower index).
+// part [nchunk][n1] int4 {best, second, arg, 0} with true scores.
+constexpr int kSiftWaveRows = 64;            // rows of a wavefront (2 MFMA row tiles)
+constexpr int kSiftWaves = 8;                         // wavefronts of a workgroup
+constexpr int kSiftStripe = kSiftWaves * kSiftWaveRows;   // rows of a stripe (workgroup)
+
+template <int OFF>
+__device__ __forceinline__ void sift_dma16(const uint8_t* gsrc, uint8_t* lds_wave_base) {
+  // LDS destination = wave-uniform base + OFF + lane * 16; source = gsrc + OFF (the offset counts on both sides)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, OFF, 0);
+}
+__device__ __forceinline__ void sift_dma4(const int* gsrc, int* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+__device__ __forceinline__ uint32_t sift_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+struct SiftFrag { v4i fb[4], cq[4]; };   // one column block: 4 k-chunks of the staged descriptors, 16 column constants
+template <int BLK>
+__device__ __forceinline__ void sift_read_frag(SiftFrag& f, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t cc_a) {
+  asm volatile("ds_read_b128 %0, %8 offset:%c12\n\tds_read_b128 %1, %9 offset:%c12\n\t"
+               "ds_read_b128 %4, %13 offset:%c14\n\tds_read_b128 %5, %13 offset:%c15\n\t"
+               "ds_read_b128 %2, %10 offset:%c12\n\tds_read_b128 %3, %11 offset:%c12\n\t"
+               "ds_read_b128 %6, %13 offset:%c16\n\tds_read_b128 %7, %13 offset:%c17"
+               : "=&v"(f.fb[0]), "=&v"(f.fb[1]), "=&v"(f.fb[2]), "=&v"(f.fb[3]), "=&v"(f.cq[0]), "=&v"(f.cq[1]), "=&v"(f.cq[2]), "=&v"(f.cq[3])
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(BLK * 4096), "v"(cc_a), "n"(BLK * 128), "n"(BLK * 128 + 32),
+                 "n"(BLK * 128 + 64), "n"(BLK * 128 + 96)
+               : "memory");
+}
+
+// xr / ccr: the row image in the prepared copy (its first row) and its constants; xc / ccc: the column image
+__device__ __forceinline__ void sift_rows(const uint8_t* __restrict__ xr, const int* __restrict__ ccr, int n1,
+                                          const uint8_t* __restrict__ xc, const int* __restrict__ ccc, int nbx,
+                                          int4* __restrict__ part, int ct_per_chunk, const int chunk, const int by) {
+  __shared__ __attribute__((aligned(16))) uint8_t sB[2][kSiftTile * 128];
+  __shared__ __attribute__((aligned(16))) int sCc[2][kSiftTile];
+  const int row0 = by * kSiftStripe;
   const int bx0 = chunk * ct_per_chunk, bx1 = min(bx0 + ct_per_chunk, nbx);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
   if (bx0 >= bx1) return;
+  const bool active = row0 + wave * kSiftWaveRows < n1;   // wave-uniform: a wavefront without rows only stages
 
-  uint4 pre[4];
-  int presum = 0;
-  auto fetch_b = [&](int bx) {
-    const int col0 = bx * kSiftTile;
+  // staging: wavefront w moves 128 / kSiftWaves rows of a tile, 8 rows per instruction: lane L of instruction j fills
+  // position L & 7 of tile row 8 (kDma w + j) + (L >> 3) (r = its place in the 32-row block), which holds chunk
+  // (L & 7) ^ swz(r) of the descriptor;
+  // wavefronts 0 / 1 move the tile's 128 constants.  swz(r) = (bit 4, bit 3, bit 1) of r: ds_read_b128 serves the lanes
+  // {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} of a half together (MI355X LDS banking), and over each of these sets
+  // (row parity, chunk ^ swz(row)) takes 16 different values = all 64 banks once.
+  constexpr int kDma = 16 / kSiftWaves;   // DMA instructions per wavefront and tile (8 rows each)
+  uint32_t goff[kDma];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int c = tid + it * 256, r = c >> 3, q = c & 7;
-      pre[it] = make_uint4(0, 0, 0, 0);
-      if (col0 + r < n2) pre[it] = *reinterpret_cast<const uint4*>(d2 + (size_t)(col0 + r) * 128 + q * 16);
-    }
-    presum = (tid < kSiftTile && col0 + tid < n2) ? sum2[col0 + tid] : 0;
-  };
-  auto store_b = [&](int buf) {
+  for (int j = 0; j < kDma; ++j) {
+    const int row = wave * (8 * kDma) + 8 * j + (lane >> 3), r = row & 31;
+    goff[j] = (uint32_t)row * 128u + (uint32_t)(((lane & 7) ^ (((r >> 2) & 6) | ((r >> 1) & 1))) * 16);
+  }
+  auto issue = [&](int bx, int buf) {
+    if (PCD_SIFT_ABLATE & 4) return;
+    const uint8_t* g = xc + (size_t)bx * (kSiftTile * 128);   // wave-uniform base + 32-bit lane offsets
+    uint8_t* l = sB[buf] + wave * (1024 * kDma);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int c = tid + it * 256, r = c >> 3, q = c & 7;
-      uint4 v = pre[it];
-      v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
-      *reinterpret_cast<uint4*>(sB[buf] + r * kSiftPitch + q * 16) = v;
-    }
-    if (tid < kSiftTile) sSumB[buf][tid] = presum;
+    for (int j = 0; j < kDma; ++j) sift_dma16<0>(g + goff[j], l + 1024 * j);
+    if (wave < 2) sift_dma4(ccc + (size_t)bx * kSiftTile + wave * 64 + lane, &sCc[buf][wave * 64]);
   };
-  fetch_b(bx0);
-  // the wavefront's set-1 fragments, straight from global memory (rows past n1: zero descriptors, score 0)
+  issue(bx0, 0);
+
+  // the wavefront's row fragments and row constants (rows past n1 are padding or another image's rows: never written)
   v4i fa[2][4];
+  int rowc[2];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int nt = 0; nt < 2; ++nt) {
+    const size_t r = (size_t)row0 + wave * kSiftWaveRows + nt * 32 + lr;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int r = row0 + wr * 64 + mt * 32 + lr;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (r < n1) v = *reinterpret_cast<const uint4*>(d1 + (size_t)r * 128 + kk * 32 + lh * 16);
-      fa[mt][kk] = v4i{(int)(v.x ^ 0x80808080u), (int)(v.y ^ 0x80808080u), (int)(v.z ^ 0x80808080u), (int)(v.w ^ 0x80808080u)};
+      const uint4 v = *reinterpret_cast<const uint4*>(xr + r * 128 + kk * 32 + lh * 16);
+      fa[nt][kk] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
     }
-  if (tid < kSiftTile) {
-    // row t of the tile sits in register k = (r & 3) + 4 (r >> 3) of lane half (r >> 2) & 1, r = t & 31
-    const int r = tid & 31;
-    sRc[tid >> 6][(r >> 2) & 1][((tid >> 5) & 1) * 16 + (r & 3) + 4 * (r >> 3)] = row0 + tid < n1 ? 128 * sum1[row0 + tid] : 0;
+    rowc[nt] = ccr[r] + kSiftConst;
   }
-  store_b(0);
+  // running state per row tile, relative to the row constant: true score 0 = -rowc, code -1 = "no column" (sift.cc:66-68)
+  int m1[2], m2[2], arg[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) { m1[nt] = -rowc[nt]; m2[nt] = -rowc[nt]; arg[nt] = -1; }
+
+  // fragment addresses inside a tile buffer: row lr of a block, k-chunk 2 kk + lh at position (2 kk + lh) ^ swz(lr)
+  uint32_t foff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    foff[kk] = (uint32_t)lr * 128u + (uint32_t)(((2 * kk + lh) ^ (((lr >> 2) & 6) | ((lr >> 1) & 1))) * 16);
+  const uint32_t sB_base = sift_lds_addr(&sB[0][0]), sCc_base = sift_lds_addr(&sCc[0][0]) + (uint32_t)lh * 16u;
+
+  // thr: what a score has to beat to matter -- the lane's own second best, or the second best of the row's other lane
+  // half minus one (refreshed once per tile): a score below the other half's second best is below the row's final one.
+  int thr[2] = {m2[0], m2[1]};
+  auto slow = [&](const int v, const int j, const int code_s) {
+    // volatile: the instructions must stay behind the branch (they are cheap enough to be if-converted)
+    int code;   // (a v_cndmask cannot take an SGPR next to VCC: the code goes through a VGPR)
+    asm volatile("v_mov_b32 %[c], %[code]\n\t"
+                 "v_cmp_gt_i32 vcc, %[v], %[b]\n\t"
+                 "v_cndmask_b32 %[a], %[a], %[c], vcc\n\t"
+                 "v_med3_i32 %[s], %[b], %[s], %[v]\n\t"
+                 "v_max_i32 %[b], %[b], %[v]\n\t"
+                 "v_max_i32 %[t], %[t], %[s]"
+                 : [b] "+v"(m1[j]), [s] "+v"(m2[j]), [a] "+v"(arg[j]), [t] "+v"(thr[j]), [c] "=&v"(code)
+                 : [v] "v"(v), [code] "s"(code_s)
+                 : "vcc");
+  };
+  auto scan_block = [&](const v16i (&acc)[2], const int seq) {
+    if (PCD_SIFT_ABLATE & 1) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); return; }
+    const int base = __builtin_amdgcn_readfirstlane(seq * 16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        unsigned long long mk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (PCD_SIFT_ABLATE & 64) { asm volatile("s_mov_b64 %0, 0" : "=s"(mk[k])); continue; }   // no compares
+          mk[k] = __builtin_amdgcn_ballot_w64(acc[j][8 * g + k] > thr[j]);
+        }
+        if (PCD_SIFT_ABLATE & 32) {   // compares only
+#pragma unroll
+          for (int k = 0; k < 8; ++k) asm volatile("" ::"s"(mk[k]));
+          continue;
+        }
+        // one scalar test per PAIR of registers (s_or_b64 sets SCC); unlikely: the fast path must be the fall-through
+        // (a taken branch costs an instruction refetch)
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          if (!(PCD_SIFT_ABLATE & 2) && __builtin_expect((mk[k] | mk[k + 1]) != 0, 0)) {
+            if (mk[k]) slow(acc[j][8 * g + k], j, base + 8 * g + k);
+            if (mk[k + 1]) slow(acc[j][8 * g + k + 1], j, base + 8 * g + k + 1);
+          }
+        }
+      }
+  };
+  // once per tile: the other lane half's second best (v_permlane32_swap: lanes 32 .. 63 of one copy <-> lanes 0 .. 31 of
+  // the other)
+  auto share_thr = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)m2[j], (unsigned)m2[j], false, false);
+      const int other = lh ? (int)sw[0] : (int)sw[1];
+      thr[j] = max(thr[j], other - 1);
+    }
+  };
+
+  v16i acc0[2];
+  // fragments of one column block: 4 k-chunks of the staged descriptors + the 16 column constants
+  // (inline-asm LDS reads: for an ordinary LDS load hipcc would first drain the DMAs in flight with vmcnt(0))
+  auto read_frag = [&](SiftFrag& f, const uint32_t fb_a, const uint32_t cc_a, auto blk_tag) {
+    if (PCD_SIFT_ABLATE & 128) {   // fragments read once; opaque "new values" so that the MFMAs stay in the loop
+      asm volatile("" : "+v"(f.fb[0]), "+v"(f.fb[1]), "+v"(f.fb[2]), "+v"(f.fb[3]), "+v"(f.cq[0]), "+v"(f.cq[1]), "+v"(f.cq[2]), "+v"(f.cq[3]));
+      return;
+    }
+    sift_read_frag<decltype(blk_tag)::value>(f, fb_a + foff[0], fb_a + foff[1], fb_a + foff[2], fb_a + foff[3], cc_a);
+    // the reads have landed (the asm ties the wait to the registers: nothing that uses them moves above it)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.fb[0]), "+v"(f.fb[1]), "+v"(f.fb[2]), "+v"(f.fb[3]), "+v"(f.cq[0]), "+v"(f.cq[1]), "+v"(f.cq[2]), "+v"(f.cq[3])
+                 :: "memory");
+  };
+  auto mfma_block = [&](v16i (&acc)[2], const SiftFrag& f) {
+    // register 4 q + i of the result = column 8 q + 4 lh + i of the block
+    v16i cc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { cc[4 * q] = f.cq[q][0]; cc[4 * q + 1] = f.cq[q][1]; cc[4 * q + 2] = f.cq[q][2]; cc[4 * q + 3] = f.cq[q][3]; }
+    if (PCD_SIFT_ABLATE & 16) return;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.fb[kk], fa[j][kk], kk == 0 ? cc : acc[j], 0, 0, 0);
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (bx0 + 1 < bx1) fetch_b(bx0 + 1);
-
-  // running row-direction state: packed (true score << 8 | 255 - sequence number); 0 = score 0, no column
-  int rbest[2][16], rsec[2][16];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { rbest[mt][k] = 0; rsec[mt][k] = 0; }
-
-  const v4i* rcp = reinterpret_cast<const v4i*>(&sRc[wr][lh][0]);
-  auto mfma_block = [&](v16i (&acc)[2], int buf, int blk) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const v4i t = rcp[mt * 4 + q];
-        acc[mt][4 * q] = t[0]; acc[mt][4 * q + 1] = t[1]; acc[mt][4 * q + 2] = t[2]; acc[mt][4 * q + 3] = t[3];
-      }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const v4i fb = *reinterpret_cast<const v4i*>(sB[buf] + (wc * 64 + blk * 32 + lr) * kSiftPitch + kk * 32 + lh * 16);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mt][kk], fb, acc[mt], 0, 0, 0);
-    }
-  };
-  // cc = the block's column constant 128 rowsum2 - 128^3 of the lane's column (read while the tile's buffer is live)
-  auto scan_block = [&](const v16i (&acc)[2], int cc, int bx, int blk, int seq) {
-    const int init = (int)((unsigned)(-cc) << 8);   // true score 0, code 0 = "no row" (sift.cc:66-68)
-    int cbest = init, csec = init;
-    const int K = (int)((unsigned)cc << 8) + (255 - seq);
-    int tv, tw;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        // 6 VALU per accumulator: v_lshl_add_u32 (pack), v_med3_i32, v_max_i32 for each direction.  Inline asm: hipcc
-        // splits the packs into a shared shift + or + add + add3 (8 per accumulator), and on gfx950 every one of these
-        // integer ops issues at half rate (tools/ubench/valu_rate3.hip: 4.4 cycles per wave64 instruction) -- the scan,
-        // not the MFMAs (36 cycles per 32x32x32), bounds the kernel.
-        // column direction: rows of one lane differ in mt / reg only, so the code is an inline constant
-        asm("v_lshl_add_u32 %2, %3, 8, %4\n\tv_med3_i32 %1, %0, %1, %2\n\tv_max_i32 %0, %0, %2"
-            : "+v"(cbest), "+v"(csec), "=&v"(tv)
-            : "v"(acc[mt][reg]), "n"(64 - (mt * 32 + (reg & 3) + 8 * (reg >> 2))));
-        // row direction
-        asm("v_lshl_add_u32 %2, %3, 8, %4\n\tv_med3_i32 %1, %0, %1, %2\n\tv_max_i32 %0, %0, %2"
-            : "+v"(rbest[mt][reg]), "+v"(rsec[mt][reg]), "=&v"(tw)
-            : "v"(acc[mt][reg]), "v"(K));
-      }
-    // the two lane halves hold interleaved rows (row = ... + 4 lh) of the same column: code -> 68 - row in the
-    // wavefront's 64 rows (the "no row" code stays below every real one)
-    cbest += 4 * (1 - lh); csec += 4 * (1 - lh);
-    {
-      const int b2 = __shfl_xor(cbest, 32), s2 = __shfl_xor(csec, 32);
-      csec = max(max(csec, s2), min(cbest, b2));
-      cbest = max(cbest, b2);
-    }
-    // packed (score - column constant) << 8 | 68 - row in the 64-row group: decoded in sift_finalize
-    const int gcol = bx * kSiftTile + wc * 64 + blk * 32 + lr;
-    if (lh == 0 && gcol < n2) part21[(size_t)(by * 2 + wr) * n2 + gcol] = make_int2(cbest, csec);
-  };
-
-  v16i acc0[2], acc1[2];
-  mfma_block(acc0, 0, 0);
+  SiftFrag f;
+  if (PCD_SIFT_ABLATE & 128) sift_read_frag<0>(f, sB_base + foff[0], sB_base + foff[1], sB_base + foff[2], sB_base + foff[3], sCc_base);
   for (int bx = bx0; bx < bx1; ++bx) {
-    const int buf = (bx - bx0) & 1;
-    const int cc0 = 128 * sSumB[buf][wc * 64 + lr] - kSiftConst, cc1 = 128 * sSumB[buf][wc * 64 + 32 + lr] - kSiftConst;
-    mfma_block(acc1, buf, 1);
-    scan_block(acc0, cc0, bx, 0, 2 * (bx - bx0));
-    if (bx + 1 < bx1) store_b(buf ^ 1);
-    __syncthreads();
-    if (bx + 2 < bx1) fetch_b(bx + 2);
-    mfma_block(acc0, buf ^ 1, 0);   // (after the last tile: the previous tile once more, unused -- keeps the MFMAs and the scan in one block)
-    scan_block(acc1, cc1, bx, 1, 2 * (bx - bx0) + 1);
+    const int t = bx - bx0, buf = t & 1;
+    if (bx + 1 < bx1) issue(bx + 1, buf ^ 1);   // the buffer's last readers passed the barrier below
+    if (active) {
+      share_thr();
+      const uint32_t fb_a = sB_base + (uint32_t)buf * (kSiftTile * 128);
+      const uint32_t cc_a = sCc_base + (uint32_t)buf * (kSiftTile * 4);
+      read_frag(f, fb_a, cc_a, std::integral_constant<int, 0>{});
+      mfma_block(acc0, f);
+      scan_block(acc0, 4 * t);
+      read_frag(f, fb_a, cc_a, std::integral_constant<int, 1>{});
+      mfma_block(acc0, f);
+      scan_block(acc0, 4 * t + 1);
+      read_frag(f, fb_a, cc_a, std::integral_constant<int, 2>{});
+      mfma_block(acc0, f);
+      scan_block(acc0, 4 * t + 2);
+      read_frag(f, fb_a, cc_a, std::integral_constant<int, 3>{});
+      mfma_block(acc0, f);
+      scan_block(acc0, 4 * t + 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's part of the next tile has landed
+    if (!(PCD_SIFT_ABLATE & 8)) __syncthreads();
   }
+  if (!active) return;
 
-  // ---- end of the walk: merge the 32 lanes that share a row (through the tile buffers), then the two wavefronts that
-  // share the stripe's rows
-  __syncthreads();   // every wavefront is done with sB
-  int2* tbuf = reinterpret_cast<int2*>(&sB[0][0]) + wave * (32 * 33);   // 32 rows x 33 (pitch) per wavefront: 8448 B of 9216
-  int rb[2], rs[2], ra[2];
+  // ---- end of the walk: decode, merge the two lane halves of a row, write the chunk's partial
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg)
-      tbuf[((reg & 3) + 8 * (reg >> 2) + 4 * lh) * 33 + lr] = make_int2(rbest[mt][reg], rsec[mt][reg]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the region is this wavefront's own: program order is enough
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // lane (rho = lr, h = lh) merges columns 16 h .. 16 h + 15 of row rho in ascending order
-    int best = 0, second = 0, arg = -1;
-#pragma unroll 4
-    for (int c = 16 * lh; c < 16 * lh + 16; ++c) {
-      const int2 e = tbuf[lr * 33 + c];
-      const int sc = e.x >> 8, seq = 255 - (e.x & 255);
-      const int col = (bx0 + (seq >> 1)) * kSiftTile + wc * 64 + (seq & 1) * 32 + c;
-      top2_merge(sc, e.y >> 8, sc > 0 ? col : -1, best, second, arg);
+  for (int nt = 0; nt < 2; ++nt) {
+    int best = m1[nt] + rowc[nt], second = m2[nt] + rowc[nt], a = -1;
+    if (arg[nt] >= 0) {
+      const int seq = arg[nt] >> 4, reg = arg[nt] & 15;
+      a = (bx0 + (seq >> 2)) * kSiftTile + (seq & 3) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
     }
-    {
-      const int b2 = __shfl_xor(best, 32), s2 = __shfl_xor(second, 32), a2 = __shfl_xor(arg, 32);
-      top2_merge(b2, s2, a2, best, second, arg);
-    }
-    rb[mt] = best; rs[mt] = second; ra[mt] = arg;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-    if (wc == 1 && lh == 0) sMerge[wr][mt * 32 + lr] = make_int4(rb[mt], rs[mt], ra[mt], 0);
-  __syncthreads();
-  if (wc == 0 && lh == 0) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int4 o = sMerge[wr][mt * 32 + lr];
-      top2_merge(o.x, o.y, o.z, rb[mt], rs[mt], ra[mt]);
-      const int grow = row0 + wr * 64 + mt * 32 + lr;
-      if (grow < n1) part12[(size_t)chunk * n1 + grow] = make_int4(rb[mt], rs[mt], ra[mt], 0);
-    }
+    const int b2 = __shfl_xor(best, 32), s2 = __shfl_xor(second, 32), a2 = __shfl_xor(a, 32);
+    top2_merge(b2, s2, a2, best, second, a);
+    const int grow = row0 + wave * kSiftWaveRows + nt * 32 + lr;
+    if (lh == 0 && grow < n1) part[(size_t)chunk * n1 + grow] = make_int4(best, second, a, 0);
   }
 }
 
-__global__ __launch_bounds__(256, PCD_SIFT_WGS) void k_sift_scores_stripe(const uint8_t* __restrict__ d1, int n1,
-                                                            const uint8_t* __restrict__ d2, int n2,
-                                                            const int* __restrict__ sum1, const int* __restrict__ sum2,
-                                                            int4* __restrict__ part12, int2* __restrict__ part21,
-                                                            int nbx, int ct_per_chunk) {
-  sift_stripe(d1, n1, d2, n2, sum1, sum2, part12, part21, nbx, ct_per_chunk, blockIdx.x, blockIdx.y);
+// blockIdx.z = direction: 0 = rows of set 1 over the columns of set 2 (part12), 1 = the sets exchanged (part21).
+// ct12 / ct21: column tiles per chunk of the two directions; workgroups past a direction's stripes or chunks leave.
+__global__ __launch_bounds__(64 * kSiftWaves, PCD_SIFT_WGS) void k_sift_scores_stripe(const uint8_t* __restrict__ xa,
+                                                            const int* __restrict__ cc, uint32_t prow1, int n1,
+                                                            uint32_t prow2, int n2, int4* __restrict__ part12,
+                                                            int4* __restrict__ part21, int ct12, int ct21) {
+  // (one call site: the walk is ~20 KB of code)
+  const bool fwd = blockIdx.z == 0;
+  const uint32_t pr = fwd ? prow1 : prow2, pc = fwd ? prow2 : prow1;
+  const int nr = fwd ? n1 : n2, nc = fwd ? n2 : n1;
+  if ((int)blockIdx.y * kSiftStripe >= nr) return;
+  sift_rows(xa + (size_t)pr * 128, cc + pr, nr, xa + (size_t)pc * 128, cc + pc, (nc + kSiftTile - 1) / kSiftTile,
+            fwd ? part12 : part21, fwd ? ct12 : ct21, blockIdx.x, blockIdx.y);
 }
 
 // ---- many image pairs in one launch set (pcd_sift_match_batch_device) ----------------------------------
-// All descriptors live in one arena; a pair names two row ranges of it.  blockIdx.z = pair; the grid's x / y
-// extents are sized for the largest pair of the batch, smaller pairs leave early.
+// All descriptors live in one arena; a pair names two row ranges of it.  blockIdx.z = 2 pair + direction; the grid's
+// x / y extents are sized for the largest set of the batch, smaller ones leave early.
 struct SiftPairDev {
-  uint32_t row1, n1, row2, n2;   // arena rows of the two images
-  uint64_t part12, part21;       // int4 / int2 offsets of the pair's partial results
+  uint32_t prow1, n1, prow2, n2; // rows of the two images in the prepared copy, their sizes
+  uint64_t part12, part21;       // int4 offsets of the pair's partial results
   uint64_t m12, m21;             // int offsets of the pair's best-match arrays
   uint64_t match;                // offset (in matches) of the pair's output list
 };
 
-__global__ __launch_bounds__(256, PCD_SIFT_WGS) void k_sift_scores_batch(const uint8_t* __restrict__ arena,
-                                                           const int* __restrict__ sum,
+__global__ __launch_bounds__(64 * kSiftWaves, PCD_SIFT_WGS) void k_sift_scores_batch(const uint8_t* __restrict__ xa,
+                                                           const int* __restrict__ cc,
                                                            const SiftPairDev* __restrict__ pairs,
-                                                           int4* __restrict__ part12, int2* __restrict__ part21,
+                                                           int4* __restrict__ part12, int4* __restrict__ part21,
                                                            int nchunk) {
-  const SiftPairDev pr = pairs[blockIdx.z];
-  const int nbx = ((int)pr.n2 + kSiftTile - 1) / kSiftTile, nby = ((int)pr.n1 + kSiftTile - 1) / kSiftTile;
-  if ((int)blockIdx.y >= nby) return;
-  const int ct = (nbx + nchunk - 1) / nchunk;   // chunks past the pair's last column tile leave inside sift_stripe
-  sift_stripe(arena + (size_t)pr.row1 * 128, (int)pr.n1, arena + (size_t)pr.row2 * 128, (int)pr.n2, sum + pr.row1,
-              sum + pr.row2, part12 + pr.part12, part21 + pr.part21, nbx, ct, blockIdx.x, blockIdx.y);
+  const SiftPairDev pr = pairs[blockIdx.z >> 1];
+  const bool fwd = (blockIdx.z & 1) == 0;
+  const uint32_t rr = fwd ? pr.prow1 : pr.prow2, rc = fwd ? pr.prow2 : pr.prow1;
+  const int nr = (int)(fwd ? pr.n1 : pr.n2), nc = (int)(fwd ? pr.n2 : pr.n1);
+  if ((int)blockIdx.y * kSiftStripe >= nr) return;
+  const int nb = (nc + kSiftTile - 1) / kSiftTile;   // chunks past the last column tile leave inside sift_rows
+  sift_rows(xa + (size_t)rr * 128, cc + rr, nr, xa + (size_t)rc * 128, cc + rc, nb,
+            fwd ? part12 + pr.part12 : part21 + pr.part21, (nb + nchunk - 1) / nchunk, blockIdx.x, blockIdx.y);
 }
 
 // sift.cc:72-104: merge the per-tile triples in ascending tile order, then the distance / ratio tests.
 // One launch for both directions: threads [0, n1) finish set 1 -> 2, threads [n1, n1 + n2) set 2 -> 1.
-__device__ __forceinline__ void sift_finalize(const int4* __restrict__ part12, int n1, int nbx,
-                                              const int2* __restrict__ part21, int n2, int nby,
-                                              const int* __restrict__ sum2, float max_ratio,
+__device__ __forceinline__ void sift_finalize(const int4* __restrict__ part12, int n1, int nc12,
+                                              const int4* __restrict__ part21, int n2, int nc21, float max_ratio,
                                               float max_distance, int* __restrict__ m12, int* __restrict__ m21) {
-  // 16 lanes per descriptor: lane p merges tiles p, p + 16, ... in ascending order, then a 4-step butterfly.
-  // On equal best scores the lower index wins, which is the earlier tile (indices ascend with the tile) --
+  // 16 lanes per descriptor: lane p merges chunks p, p + 16, ... in ascending order, then a 4-step butterfly.
+  // On equal best scores the lower index wins, which is the earlier chunk (indices ascend with the chunk) --
   // the same winner as the reference's single ascending scan.
   const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, p = threadIdx.x & 15;
   if (g >= n1 + n2) return;
   const bool first = g < n1;
   const int i = first ? g : g - n1;
+  const int4* __restrict__ part = first ? part12 : part21;
+  const int n = first ? n1 : n2, nc = first ? nc12 : nc21;
   int best = 0, second = 0, arg = -1;
-  if (first) {
-    for (int b = p; b < nbx; b += 16) {
-      const int4 v = part12[(size_t)b * n1 + i];
-      top2_merge(v.x, v.y, v.z, best, second, arg);
-    }
-  } else {
-    // column direction: partial b = the 64-row group b (rows 64 b ..); packed (score - cc) << 8 | 68 - row in the group
-    const int cc = 128 * sum2[i] - kSiftConst;
-    for (int b = p; b < nby; b += 16) {
-      const int2 v = part21[(size_t)b * n2 + i];
-      const int bs = (v.x >> 8) + cc, ss = (v.y >> 8) + cc;   // true scores (>= 0)
-      top2_merge(bs, ss, bs > 0 ? b * 64 + 68 - (v.x & 255) : -1, best, second, arg);
-    }
+  for (int b = p; b < nc; b += 16) {
+    const int4 v = part[(size_t)b * n + i];
+    top2_merge(v.x, v.y, v.z, best, second, arg);
   }
 #pragma unroll
   for (int o = 1; o < 16; o <<= 1) {
@@ -354,25 +442,28 @@ __device__ __forceinline__ void sift_finalize(const int4* __restrict__ part12, i
   (first ? m12 : m21)[i] = m;
 }
 
-__global__ __launch_bounds__(256) void k_sift_finalize(const int4* __restrict__ part12, int n1, int nbx,
-                                                       const int2* __restrict__ part21, int n2, int nby,
-                                                       const int* __restrict__ sum2, float max_ratio,
-                                                       float max_distance, int* __restrict__ m12,
+// chunks of a walk over nb column tiles cut into nchunk pieces that wrote a partial
+__host__ __device__ __forceinline__ int sift_chunks_used(int nb, int nchunk) {
+  const int ct = (nb + nchunk - 1) / nchunk;
+  return ct > 0 ? (nb + ct - 1) / ct : 0;
+}
+
+__global__ __launch_bounds__(256) void k_sift_finalize(const int4* __restrict__ part12, int n1, int nc12,
+                                                       const int4* __restrict__ part21, int n2, int nc21,
+                                                       float max_ratio, float max_distance, int* __restrict__ m12,
                                                        int* __restrict__ m21) {
-  sift_finalize(part12, n1, nbx, part21, n2, nby, sum2, max_ratio, max_distance, m12, m21);
+  sift_finalize(part12, n1, nc12, part21, n2, nc21, max_ratio, max_distance, m12, m21);
 }
 
 __global__ __launch_bounds__(256) void k_sift_finalize_batch(const SiftPairDev* __restrict__ pairs,
-                                                             const int* __restrict__ sum,
                                                              const int4* __restrict__ part12,
-                                                             const int2* __restrict__ part21, int nchunk,
+                                                             const int4* __restrict__ part21, int nchunk,
                                                              float max_ratio, float max_distance, int* __restrict__ m12,
                                                              int* __restrict__ m21) {
   const SiftPairDev pr = pairs[blockIdx.z];
-  const int nbx = ((int)pr.n2 + kSiftTile - 1) / kSiftTile, nby = ((int)pr.n1 + kSiftTile - 1) / kSiftTile;
-  const int ct = max(1, (nbx + nchunk - 1) / nchunk), used = (nbx + ct - 1) / ct;   // chunks that wrote a partial
-  sift_finalize(part12 + pr.part12, (int)pr.n1, used, part21 + pr.part21, (int)pr.n2, 2 * nby, sum + pr.row2, max_ratio,
-                max_distance, m12 + pr.m12, m21 + pr.m21);
+  const int nb1 = ((int)pr.n1 + kSiftTile - 1) / kSiftTile, nb2 = ((int)pr.n2 + kSiftTile - 1) / kSiftTile;
+  sift_finalize(part12 + pr.part12, (int)pr.n1, sift_chunks_used(nb2, nchunk), part21 + pr.part21, (int)pr.n2,
+                sift_chunks_used(nb1, nchunk), max_ratio, max_distance, m12 + pr.m12, m21 + pr.m21);
 }
 
 // sift.cc:118-143 for n1 <= 1024 * kCompactPer: cross check, ordered compaction and count in ONE workgroup
@@ -471,9 +562,12 @@ __global__ void k_sift_compact(const int* __restrict__ m12, const uint32_t* __re
 
 struct SiftScratch {
   DevBuf<uint8_t> d1, d2;
-  DevBuf<int> sum1, sum2, m12, m21, count;
-  DevBuf<int4> part12;
-  DevBuf<int2> part21;
+  DevBuf<uint8_t> xa;   // the prepared copy (k_sift_prep_*): re-centred bytes, images padded to 128 rows, + one stripe of slack
+  DevBuf<int> cc;       // its per-row constants
+  DevBuf<SiftImageDev> images;
+  PinnedBuf<SiftImageDev> h_images;
+  DevBuf<int> m12, m21, count;
+  DevBuf<int4> part12, part21;
   DevBuf<uint32_t> keep, pos, matches;
   DevBuf<char> tmp;
   // batch entry
@@ -520,32 +614,39 @@ static pcd_status sift_end_use(SiftScratch& sc, hipStream_t s) {
 static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uint8_t* d_d2, int n2, float max_ratio,
                               float max_distance, int cross_check, int* d_m12, int* d_m21, uint32_t* d_matches,
                               int* d_count, SiftScratch& sc, hipStream_t s) {
-  const int nby = (n1 + kSiftTile - 1) / kSiftTile, nbx = (n2 + kSiftTile - 1) / kSiftTile;
-  // stripe walk: enough (row tile, chunk) workgroups to fill the chip twice over
-  // (a chunk is at most 128 column tiles: the stripe kernel's 8-bit sequence code)
+  const int nb1 = (n1 + kSiftTile - 1) / kSiftTile, nb2 = (n2 + kSiftTile - 1) / kSiftTile;
+  // stripe walks in both directions: enough (row tile, chunk) workgroups to fill the chip twice over
   // pcd_sift_set_tuning (tests / fuzzing) can force the number of column chunks, e.g. 1 = every stripe walks all tiles
-  const int nchunk_env = g_sift_nchunk.load(std::memory_order_relaxed);   // pcd_sift_set_tuning (tests / fuzzing)
-  const int want = nchunk_env > 0 ? std::min(nchunk_env, nbx) : std::min(nbx, (512 + nby - 1) / nby);
-  const int nchunk = std::max({1, want, (nbx + 127) / 128});
-  const int ct_per_chunk = (nbx + nchunk - 1) / nchunk;
-  const int nchunk_used = (nbx + ct_per_chunk - 1) / ct_per_chunk;
-  PCD_TRY(sc.sum1.reserve(n1)); PCD_TRY(sc.sum2.reserve(n2));
-  PCD_TRY(sc.part12.reserve((size_t)n1 * nchunk_used)); PCD_TRY(sc.part21.reserve((size_t)n2 * nby * 2));
+  const int nchunk_set = g_sift_nchunk.load(std::memory_order_relaxed);
+  auto chunks = [&](int nrow_tiles, int ncol_tiles) {
+    const int stripes = (n1 + kSiftStripe - 1) / kSiftStripe + (n2 + kSiftStripe - 1) / kSiftStripe;
+    const int want = nchunk_set > 0 ? std::min(nchunk_set, ncol_tiles) : std::min(ncol_tiles, (512 + stripes - 1) / stripes);
+    (void)nrow_tiles;
+    return std::max(1, want);
+  };
+  const int nchunk12 = chunks(nb1, nb2), nchunk21 = chunks(nb2, nb1);
+  const int ct12 = (nb2 + nchunk12 - 1) / nchunk12, ct21 = (nb1 + nchunk21 - 1) / nchunk21;
+  const int used12 = sift_chunks_used(nb2, nchunk12), used21 = sift_chunks_used(nb1, nchunk21);
+  const uint32_t prow1 = 0, prow2 = (uint32_t)nb1 * kSiftTile;
+  const size_t prows = (size_t)(nb1 + nb2) * kSiftTile + kSiftStripe;   // a stripe's row fragments are read unconditionally
+  PCD_TRY(sc.xa.reserve(prows * 128)); PCD_TRY(sc.cc.reserve(prows));
+  PCD_TRY(sc.part12.reserve((size_t)n1 * used12)); PCD_TRY(sc.part21.reserve((size_t)n2 * used21));
   PCD_TRY(sc.keep.reserve(n1)); PCD_TRY(sc.pos.reserve(n1));
   {
-    ScopedKernelTimer t("sift_rowsum", s);
-    hipLaunchKernelGGL(k_sift_rowsum, dim3(div_up((uint64_t)n1 + n2, 256)), dim3(256), 0, s, d_d1, n1, sc.sum1.p, d_d2, n2,
-                       sc.sum2.p);
+    ScopedKernelTimer t("sift_prep", s);
+    hipLaunchKernelGGL(k_sift_prep_pair, dim3(std::max(nb1, nb2), 2), dim3(256), 0, s, SiftImageDev{d_d1, (uint32_t)n1, prow1},
+                       SiftImageDev{d_d2, (uint32_t)n2, prow2}, sc.xa.p, sc.cc.p);
   }
   {
     ScopedKernelTimer t("sift_scores", s);
-    hipLaunchKernelGGL(k_sift_scores_stripe, dim3(nchunk_used, nby), dim3(256), 0, s, d_d1, n1, d_d2, n2, sc.sum1.p,
-                       sc.sum2.p, sc.part12.p, sc.part21.p, nbx, ct_per_chunk);
+    const int ns1 = (n1 + kSiftStripe - 1) / kSiftStripe, ns2 = (n2 + kSiftStripe - 1) / kSiftStripe;
+    hipLaunchKernelGGL(k_sift_scores_stripe, dim3(std::max(used12, used21), std::max(ns1, ns2), 2), dim3(64 * kSiftWaves), 0, s, sc.xa.p,
+                       sc.cc.p, prow1, n1, prow2, n2, sc.part12.p, sc.part21.p, ct12, ct21);
   }
   {
     ScopedKernelTimer t("sift_finalize", s);
     hipLaunchKernelGGL(k_sift_finalize, dim3(div_up(((uint64_t)n1 + n2) * 16, 256)), dim3(256), 0, s, sc.part12.p, n1,
-                       nchunk_used, sc.part21.p, n2, 2 * nby, sc.sum2.p, max_ratio, max_distance, d_m12, d_m21);
+                       used12, sc.part21.p, n2, used21, max_ratio, max_distance, d_m12, d_m21);
   }
   {
     ScopedKernelTimer t("sift_compact", s);
@@ -581,7 +682,6 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
   const uint64_t budget_set = g_sift_batch_partials.load(std::memory_order_relaxed);   // pcd_sift_set_tuning
   const size_t budget = budget_set ? (size_t)budget_set : kSiftBatchPartials;
   for (int i = 0; i < n_images; ++i) PCD_REQUIRE(first_row[i] <= first_row[i + 1], "first_row must ascend");
-  uint64_t max_nbx = 1;
   bool wide = false;   // a set too long for the one-workgroup compaction: those batches run pair by pair
   for (int p = 0; p < n_pairs; ++p) {
     PCD_REQUIRE(pair_ids[2 * p] < (uint32_t)n_images && pair_ids[2 * p + 1] < (uint32_t)n_images, "pair names an image outside the arena");
@@ -589,7 +689,6 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
     const uint64_t n2 = first_row[pair_ids[2 * p + 1] + 1] - first_row[pair_ids[2 * p + 1]];
     PCD_REQUIRE(n1 < (1u << 30) && n2 < (1u << 30), "image too large");
     wide = wide || n1 > (uint64_t)1024 * kCompactPer;
-    max_nbx = std::max(max_nbx, (n2 + kSiftTile - 1) / kSiftTile);
   }
   if (wide) {
     for (int p = 0; p < n_pairs; ++p) {
@@ -603,12 +702,19 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
     }
     return PCD_OK;
   }
-  PCD_TRY(sc.sum1.reserve(total_rows));
-  if (total_rows) {
-    ScopedKernelTimer t("sift_rowsum", s);
-    hipLaunchKernelGGL(k_sift_rowsum, dim3(div_up(total_rows, 256)), dim3(256), 0, s, d_arena, (int)total_rows, sc.sum1.p,
-                       (const uint8_t*)nullptr, 0, (int*)nullptr);
+  // the prepared copy: every image padded to a multiple of 128 rows
+  std::vector<SiftImageDev> imgs((size_t)n_images);
+  uint64_t prows = 0;
+  uint32_t max_tiles = 0;
+  for (int i = 0; i < n_images; ++i) {
+    const uint64_t n = first_row[i + 1] - first_row[i];
+    imgs[i] = SiftImageDev{d_arena + first_row[i] * 128, (uint32_t)n, (uint32_t)prows};
+    const uint64_t tiles = (n + kSiftTile - 1) / kSiftTile;
+    max_tiles = std::max<uint32_t>(max_tiles, (uint32_t)tiles);
+    prows += tiles * kSiftTile;
   }
+  PCD_REQUIRE(prows + kSiftStripe < (1ull << 32), "arena larger than 2^32 descriptors");
+  PCD_TRY(sc.xa.reserve((prows + kSiftStripe) * 128)); PCD_TRY(sc.cc.reserve(prows + kSiftStripe));
   // pair table for the whole call (uploaded once; sub-batches index into it)
   std::vector<SiftPairDev> tab((size_t)n_pairs);
   std::vector<int> cut;   // sub-batch boundaries
@@ -623,22 +729,22 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
       const uint32_t a0 = pair_ids[2 * p0], b0 = pair_ids[2 * p0 + 1];
       const int nby0 = std::max<int>(1, (int)((first_row[a0 + 1] - first_row[a0] + kSiftTile - 1) / kSiftTile));
       const int nbx0 = std::max<int>(1, (int)((first_row[b0 + 1] - first_row[b0] + kSiftTile - 1) / kSiftTile));
+      const long stripes0 = (nby0 * kSiftTile + kSiftStripe - 1) / kSiftStripe + (nbx0 * kSiftTile + kSiftStripe - 1) / kSiftStripe;   // stripes of both directions
       const long left = n_pairs - p0;
       const int nchunk_env = g_sift_nchunk.load(std::memory_order_relaxed);
-      const long want = nchunk_env > 0 ? std::min<long>(nchunk_env, nbx0) : std::min<long>(nbx0, (512 + nby0 * left - 1) / (nby0 * left));
-      const int nchunk = (int)std::max<long>({1, want, (long)((max_nbx + 127) / 128)});   // a chunk is at most 128 column tiles
+      const long want = nchunk_env > 0 ? std::min<long>(nchunk_env, std::max(nbx0, nby0))
+                                       : std::min<long>(std::max(nbx0, nby0), (512 + stripes0 * left - 1) / (stripes0 * left));
+      const int nchunk = (int)std::max<long>(1, want);
       size_t o12 = 0, o21 = 0, om12 = 0, om21 = 0;
       int p = p0;
       for (; p < n_pairs; ++p) {
         const uint32_t a = pair_ids[2 * p], b = pair_ids[2 * p + 1];
         uint64_t n1 = first_row[a + 1] - first_row[a], n2 = first_row[b + 1] - first_row[b];
         if (n1 == 0 || n2 == 0) n1 = n2 = 0;   // an empty image: no matches (sift_test.cc:311-318); every kernel skips the pair
-        const size_t nby = (n1 + kSiftTile - 1) / kSiftTile;
-        const size_t need12 = (size_t)nchunk * n1, need21 = 2 * nby * n2;
-        // (the budget counts 16-byte units: part12 entries are int4, part21 entries int2)
-        if (p > p0 && (o12 + need12 + (o21 + need21 + 1) / 2 > budget || p - p0 >= 65535)) break;
-        tab[p] = SiftPairDev{(uint32_t)first_row[a], (uint32_t)n1, (uint32_t)first_row[b], (uint32_t)n2, o12, o21, om12, om21,
-                             match_offset[p]};
+        const size_t need12 = (size_t)nchunk * n1, need21 = (size_t)nchunk * n2;
+        // (the budget counts 16-byte units: both partial arrays are int4; 2 z-slices per pair in the scores launch)
+        if (p > p0 && (o12 + need12 + o21 + need21 > budget || p - p0 >= 32767)) break;
+        tab[p] = SiftPairDev{imgs[a].prow, (uint32_t)n1, imgs[b].prow, (uint32_t)n2, o12, o21, om12, om21, match_offset[p]};
         o12 += need12; o21 += need21; om12 += n1; om21 += n2;
       }
       max12 = std::max(max12, o12); max21 = std::max(max21, o21);
@@ -654,11 +760,17 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
   // the table goes up ON THE CALLER'S STREAM (a null-stream copy is not ordered against a non-blocking stream: a second
   // call could overwrite sc.pairs under the first call's kernels); pinned staging, guarded by ev_tab
   if (sc.tab_pending) PCD_HIP_TRY(hipEventSynchronize(sc.ev_tab));
-  PCD_TRY(sc.h_pairs.reserve(n_pairs));
+  PCD_TRY(sc.h_pairs.reserve(n_pairs)); PCD_TRY(sc.h_images.reserve(n_images)); PCD_TRY(sc.images.reserve(n_images));
   std::memcpy(sc.h_pairs.p, tab.data(), sizeof(SiftPairDev) * (size_t)n_pairs);
+  std::memcpy(sc.h_images.p, imgs.data(), sizeof(SiftImageDev) * (size_t)n_images);
   PCD_HIP_TRY(hipMemcpyAsync(sc.pairs.p, sc.h_pairs.p, sizeof(SiftPairDev) * (size_t)n_pairs, hipMemcpyHostToDevice, s));
+  PCD_HIP_TRY(hipMemcpyAsync(sc.images.p, sc.h_images.p, sizeof(SiftImageDev) * (size_t)n_images, hipMemcpyHostToDevice, s));
   PCD_HIP_TRY(hipEventRecord(sc.ev_tab, s));
   sc.tab_pending = true;
+  if (max_tiles) {
+    ScopedKernelTimer t("sift_prep", s);
+    hipLaunchKernelGGL(k_sift_prep_images, dim3(max_tiles, n_images), dim3(256), 0, s, sc.images.p, sc.xa.p, sc.cc.p);
+  }
   for (size_t k = 0; k + 1 < cut.size(); ++k) {
     const int p0 = cut[k], np = cut[k + 1] - cut[k], nchunk = cut_nchunk[k];
     uint32_t mx1 = 0, mx2 = 0, mxsum = 0;
@@ -668,13 +780,13 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
     if (mx1 && mx2) {
       {
         ScopedKernelTimer t("sift_scores", s);
-        hipLaunchKernelGGL(k_sift_scores_batch, dim3(nchunk, (mx1 + kSiftTile - 1) / kSiftTile, np), dim3(256), 0, s, d_arena,
-                           sc.sum1.p, sc.pairs.p + p0, sc.part12.p, sc.part21.p, nchunk);
+        hipLaunchKernelGGL(k_sift_scores_batch, dim3(nchunk, (std::max(mx1, mx2) + kSiftStripe - 1) / kSiftStripe, 2 * np),
+                           dim3(64 * kSiftWaves), 0, s, sc.xa.p, sc.cc.p, sc.pairs.p + p0, sc.part12.p, sc.part21.p, nchunk);
       }
       {
         ScopedKernelTimer t("sift_finalize", s);
         hipLaunchKernelGGL(k_sift_finalize_batch, dim3(div_up((uint64_t)mxsum * 16, 256), 1, np), dim3(256), 0, s,
-                           sc.pairs.p + p0, sc.sum1.p, sc.part12.p, sc.part21.p, nchunk, max_ratio, max_distance, sc.m12.p, sc.m21.p);
+                           sc.pairs.p + p0, sc.part12.p, sc.part21.p, nchunk, max_ratio, max_distance, sc.m12.p, sc.m21.p);
       }
     }
     {
