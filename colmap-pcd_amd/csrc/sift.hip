@@ -272,7 +272,8 @@ __device__ __forceinline__ void sift_rows(const uint8_t* __restrict__ xr, const 
           for (int k = 0; k < 8; ++k) asm volatile("" ::"s"(mk[k]));
           continue;
         }
-        // one scalar test per PAIR of registers (s_or_b64 sets SCC); unlikely: the fast path must be the fall-through
+        // one scalar test per PAIR of registers (asm goto, which would save the s_cmp behind the s_or, is miscompiled by
+        // this hipcc: the asm body is dropped); unlikely: the fast path must be the fall-through
         // (a taken branch costs an instruction refetch)
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {

@@ -2,6 +2,7 @@
 // hipcc --offload-arch=gfx950 -O3 valu_rate3.hip -o valu_rate3
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 #define REP8(x) x x x x x x x x
@@ -43,6 +44,15 @@ __global__ __launch_bounds__(256, 4) void k(int* out, int iters, int s0) {
     if (OP == 23) { REP8(asm volatile(T8("v_perm_b32") : A8);) }
     if (OP == 24) { REP8(asm volatile(T8("v_alignbit_b32") : A8);) }
     if (OP == 25) { REP8(asm volatile(I8("v_or_b32") : A8);) }
+#define CMP8(op) op " s[40:41], %0, %1\n" op " s[42:43], %1, %2\n" op " s[44:45], %2, %3\n" op " s[46:47], %3, %4\n" op " s[48:49], %4, %5\n" op " s[50:51], %5, %6\n" op " s[52:53], %6, %7\n" op " s[54:55], %7, %0"
+#define CMPV8(op) op " vcc, %0, %1\n" op " vcc, %1, %2\n" op " vcc, %2, %3\n" op " vcc, %3, %4\n" op " vcc, %4, %5\n" op " vcc, %5, %6\n" op " vcc, %6, %7\n" op " vcc, %7, %0"
+#define SCLOB "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "vcc"
+    if (OP == 26) { REP8(asm volatile(CMP8("v_cmp_gt_i32_e64") : A8 : : SCLOB);) }
+    if (OP == 27) { REP8(asm volatile(CMPV8("v_cmp_gt_i32_e32") : A8 : : SCLOB);) }
+    if (OP == 28) { REP8(asm volatile(I8("v_sub_u32") : A8);) }
+    if (OP == 29) { REP8(asm volatile(CMP8("v_cmp_gt_u32_e64") : A8 : : SCLOB);) }
+    if (OP == 30) { REP8(asm volatile(CMP8("v_cmp_gt_i16_e64") : A8 : : SCLOB);) }
+    if (OP == 31) { REP8(asm volatile(CMP8("v_cmp_gt_f32_e64") : A8 : : SCLOB);) }
     if (OP == 7) {   // 32 accumulator values scanned in both directions: 192 VALU
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -102,6 +112,19 @@ void run(const char* name, int instr_per_iter, int w) {
 }
 
 int main() {
+  if (getenv("UBENCH_CMP_ONLY")) {
+    for (int w : {2, 4}) {
+      run<26>("v_cmp_gt_i32_e64 -> sgpr pair", 64, w);
+      run<27>("v_cmp_gt_i32_e32 -> vcc", 64, w);
+      run<28>("v_sub_u32", 64, w);
+      run<5>("v_add_u32", 64, w);
+      run<29>("v_cmp_gt_u32_e64", 64, w);
+      run<30>("v_cmp_gt_i16_e64", 64, w);
+      run<31>("v_cmp_gt_f32_e64", 64, w);
+      run<0>("v_max_i32", 64, w);
+    }
+    return 0;
+  }
   for (int w : {2, 4}) {
     run<0>("v_max_i32", 64, w);
     run<1>("v_med3_i32", 64, w);
