@@ -42,11 +42,10 @@ static std::atomic<uint64_t> g_sift_batch_partials{0};
 constexpr int kSiftTile = 128;
 constexpr int kSiftConst = 128 * 128 * 128;
 #ifndef PCD_SIFT_WGS
-#define PCD_SIFT_WGS 4   // (hipcc turns this into waves per SIMD for a 512-thread workgroup: 4 = two workgroups per CU)
+#define PCD_SIFT_WGS 2
 #endif
 #ifndef PCD_SIFT_ABLATE   // timing-only variants (tools/sift_ablate.sh; results are wrong): 1 no scan, 2 no slow path,
-#define PCD_SIFT_ABLATE 0 // 4 no staging of further tiles, 8 no barrier, 16 no MFMA, 32 compares only, 64 no compares, 128 fragments read once,
-                          // 256 no column compares, 512 no column slow path
+#define PCD_SIFT_ABLATE 0 // 4 no fetch / store of further tiles, 8 no barrier, 16 no MFMA
 #endif
 
 // ---- preparation: the re-centred, padded copy the walks read ------------------------------------------------------
@@ -165,20 +164,6 @@ __device__ __forceinline__ uint32_t sift_lds_addr(const void* p) {
 }
 
 struct SiftFrag { v4i fb[4], cq[4]; };   // one column block: 4 k-chunks of the staged descriptors, 16 column constants
-// one staged tile: descriptors (swizzled), column constants, column thresholds, the columns' best / second-best slots --
-// one struct so that a single per-lane address + immediate offsets reaches all of it
-struct __attribute__((aligned(16))) SiftLdsBuf {
-  uint8_t b[kSiftTile * 128];
-  int cc[kSiftTile];
-  int thr[kSiftTile];
-  unsigned long long cb[kSiftTile];
-  int cs[kSiftTile];
-};
-constexpr int kLdsCc = kSiftTile * 128, kLdsThr = kLdsCc + kSiftTile * 4, kLdsCb = kLdsThr + kSiftTile * 4,
-              kLdsCs = kLdsCb + kSiftTile * 8;
-static_assert(sizeof(SiftLdsBuf) == kLdsCs + kSiftTile * 4, "SiftLdsBuf layout");
-
-// a0 .. a3: the lane's fragment addresses inside the tile buffer; a16: buffer + 16 x lane half
 template <int BLK>
 __device__ __forceinline__ void sift_read_frag(SiftFrag& f, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t cc_a) {
   asm volatile("ds_read_b128 %0, %8 offset:%c12\n\tds_read_b128 %1, %9 offset:%c12\n\t"
@@ -186,29 +171,17 @@ __device__ __forceinline__ void sift_read_frag(SiftFrag& f, uint32_t a0, uint32_
                "ds_read_b128 %2, %10 offset:%c12\n\tds_read_b128 %3, %11 offset:%c12\n\t"
                "ds_read_b128 %6, %13 offset:%c16\n\tds_read_b128 %7, %13 offset:%c17"
                : "=&v"(f.fb[0]), "=&v"(f.fb[1]), "=&v"(f.fb[2]), "=&v"(f.fb[3]), "=&v"(f.cq[0]), "=&v"(f.cq[1]), "=&v"(f.cq[2]), "=&v"(f.cq[3])
-               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(BLK * 4096), "v"(cc_a), "n"(kLdsCc + BLK * 128), "n"(kLdsCc + BLK * 128 + 32),
-                 "n"(kLdsCc + BLK * 128 + 64), "n"(kLdsCc + BLK * 128 + 96)
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(BLK * 4096), "v"(cc_a), "n"(BLK * 128), "n"(BLK * 128 + 32),
+                 "n"(BLK * 128 + 64), "n"(BLK * 128 + 96)
                : "memory");
 }
 
-// xr / ccr: the row image in the prepared copy (its first row) and its constants; xc / ccc: the column image.
-// COLS = false: rows only.  part == nullptr: the SEED launch -- the row's true second best goes to seed_out[row]
-// (INT_MAX for the image's padding rows), nothing else is written.
-// COLS = true: ONE product serves both directions.  The best / second-best ROW per COLUMN is kept in LDS for the staged
-// tile (sCb: (score << 32 | ~row) under ds_max_rtn_u64, sCs: the losers' maximum) and only the lanes whose score reaches
-// the column's threshold colthr[col] -- its second best over a sample of rows, the seed launch -- take part: for a
-// register that is one v_sub + one v_cmp on top of the row test.  A column's final second best is at least its second
-// best over any subset of rows, so every score that ends up as best, as second best, or ties with them passes
-// ("reaches": >=, a later equal score with a lower row must still be able to take the best place; colthr holds the
-// threshold minus one, the test is one v_cmp "score > colthr").  After the tile's
-// barrier the stripe's result for the tile's 128 columns goes to cpart[stripe][col] and the LDS state is cleared.
-template <bool COLS>
+// xr / ccr: the row image in the prepared copy (its first row) and its constants; xc / ccc: the column image
 __device__ __forceinline__ void sift_rows(const uint8_t* __restrict__ xr, const int* __restrict__ ccr, int n1,
                                           const uint8_t* __restrict__ xc, const int* __restrict__ ccc, int nbx,
-                                          int4* __restrict__ part, int ct_per_chunk, const int chunk, const int by,
-                                          int* __restrict__ seed_out, const int* __restrict__ colthr,
-                                          int4* __restrict__ cpart, int n2) {
-  __shared__ SiftLdsBuf sL[2];
+                                          int4* __restrict__ part, int ct_per_chunk, const int chunk, const int by) {
+  __shared__ __attribute__((aligned(16))) uint8_t sB[2][kSiftTile * 128];
+  __shared__ __attribute__((aligned(16))) int sCc[2][kSiftTile];
   const int row0 = by * kSiftStripe;
   const int bx0 = chunk * ct_per_chunk, bx1 = min(bx0 + ct_per_chunk, nbx);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -224,21 +197,20 @@ __device__ __forceinline__ void sift_rows(const uint8_t* __restrict__ xr, const 
   // {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} of a half together (MI355X LDS banking), and over each of these sets
   // (row parity, chunk ^ swz(row)) takes 16 different values = all 64 banks once.
   constexpr int kDma = 16 / kSiftWaves;   // DMA instructions per wavefront and tile (8 rows each)
+  uint32_t goff[kDma];
+#pragma unroll
+  for (int j = 0; j < kDma; ++j) {
+    const int row = wave * (8 * kDma) + 8 * j + (lane >> 3), r = row & 31;
+    goff[j] = (uint32_t)row * 128u + (uint32_t)(((lane & 7) ^ (((r >> 2) & 6) | ((r >> 1) & 1))) * 16);
+  }
   auto issue = [&](int bx, int buf) {
     if (PCD_SIFT_ABLATE & 4) return;
     const uint8_t* g = xc + (size_t)bx * (kSiftTile * 128);   // wave-uniform base + 32-bit lane offsets
-    uint8_t* l = sL[buf].b + wave * (1024 * kDma);
+    uint8_t* l = sB[buf] + wave * (1024 * kDma);
 #pragma unroll
-    for (int j = 0; j < kDma; ++j) {   // (the lane offsets are recomputed per tile: two registers less in the block loop)
-      const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-      const int row = wave * (8 * kDma) + 8 * j + (ln >> 3), r = row & 31;
-      const uint32_t goff = (uint32_t)row * 128u + (uint32_t)(((ln & 7) ^ (((r >> 2) & 6) | ((r >> 1) & 1))) * 16);
-      sift_dma16<0>(g + goff, l + 1024 * j);
-    }
-    if (wave < 2) sift_dma4(ccc + (size_t)bx * kSiftTile + wave * 64 + lane, &sL[buf].cc[wave * 64]);
-    if (COLS && wave >= 2 && wave < 4) sift_dma4(colthr + (size_t)bx * kSiftTile + (wave - 2) * 64 + lane, &sL[buf].thr[(wave - 2) * 64]);
+    for (int j = 0; j < kDma; ++j) sift_dma16<0>(g + goff[j], l + 1024 * j);
+    if (wave < 2) sift_dma4(ccc + (size_t)bx * kSiftTile + wave * 64 + lane, &sCc[buf][wave * 64]);
   };
-  if (COLS && tid < 2 * kSiftTile) { sL[tid >> 7].cb[tid & 127] = 0ull; sL[tid >> 7].cs[tid & 127] = 0; }   // (ordered by the first barrier)
   issue(bx0, 0);
 
   // the wavefront's row fragments and row constants (rows past n1 are padding or another image's rows: never written)
@@ -254,17 +226,21 @@ __device__ __forceinline__ void sift_rows(const uint8_t* __restrict__ xr, const 
     }
     rowc[nt] = ccr[r] + kSiftConst;
   }
-  // running state per row tile (true scores): score 0, code -1 = "no column" (sift.cc:66-68)
-  int m1[2] = {0, 0}, m2[2] = {0, 0}, arg[2] = {-1, -1};
+  // running state per row tile, relative to the row constant: true score 0 = -rowc, code -1 = "no column" (sift.cc:66-68)
+  int m1[2], m2[2], arg[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) { m1[nt] = -rowc[nt]; m2[nt] = -rowc[nt]; arg[nt] = -1; }
 
-  // addresses inside a tile buffer (recomputed per tile: fewer registers live across the block loop): the fragment of
-  // row lr of a block, k-chunk 2 kk + lh at position (2 kk + lh) ^ swz(lr); a16 = buffer + 16 x lane half reaches the
-  // constants, thresholds and second-best slots with immediate offsets, the best slots (8 bytes) from a16 + 16 x lane half
-  const uint32_t sL_base = sift_lds_addr(&sL[0]);
-  auto frag_addr = [&](int buf, int kk) {
-    return sL_base + (uint32_t)buf * (uint32_t)sizeof(SiftLdsBuf) + (uint32_t)lr * 128u +
-           (uint32_t)(((2 * kk + lh) ^ (((lr >> 2) & 6) | ((lr >> 1) & 1))) * 16);
-  };
+  // fragment addresses inside a tile buffer: row lr of a block, k-chunk 2 kk + lh at position (2 kk + lh) ^ swz(lr)
+  uint32_t foff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    foff[kk] = (uint32_t)lr * 128u + (uint32_t)(((2 * kk + lh) ^ (((lr >> 2) & 6) | ((lr >> 1) & 1))) * 16);
+  const uint32_t sB_base = sift_lds_addr(&sB[0][0]), sCc_base = sift_lds_addr(&sCc[0][0]) + (uint32_t)lh * 16u;
+
+  // thr: what a score has to beat to matter -- the lane's own second best, or the second best of the row's other lane
+  // half minus one (refreshed once per tile): a score below the other half's second best is below the row's final one.
+  int thr[2] = {m2[0], m2[1]};
   auto slow = [&](const int v, const int j, const int code_s) {
     // volatile: the instructions must stay behind the branch (they are cheap enough to be if-converted)
     int code;   // (a v_cndmask cannot take an SGPR next to VCC: the code goes through a VGPR)
@@ -272,66 +248,28 @@ __device__ __forceinline__ void sift_rows(const uint8_t* __restrict__ xr, const 
                  "v_cmp_gt_i32 vcc, %[v], %[b]\n\t"
                  "v_cndmask_b32 %[a], %[a], %[c], vcc\n\t"
                  "v_med3_i32 %[s], %[b], %[s], %[v]\n\t"
-                 "v_max_i32 %[b], %[b], %[v]"
-                 : [b] "+v"(m1[j]), [s] "+v"(m2[j]), [a] "+v"(arg[j]), [c] "=&v"(code)
+                 "v_max_i32 %[b], %[b], %[v]\n\t"
+                 "v_max_i32 %[t], %[t], %[s]"
+                 : [b] "+v"(m1[j]), [s] "+v"(m2[j]), [a] "+v"(arg[j]), [t] "+v"(thr[j]), [c] "=&v"(code)
                  : [v] "v"(v), [code] "s"(code_s)
                  : "vcc");
   };
-  // the column side of a register some lane of which reaches its column's threshold (mC): those lanes put
-  // (true score, ~row) into the column's LDS slot; what loses there -- the slot's old content or the new value -- goes
-  // to the column's second-best slot.  blk / reg fix the column (immediate offsets), cb_a / cs_a the tile buffer.
-  auto col_slow = [&](const int v, const int j, const unsigned long long mC, const uint32_t a16, const int OFF) {   // OFF: column of the register inside the tile, without the lane half (a constant after unrolling)
-    const int hi = v;                               // (true score)
-    (void)rowc;
-    const unsigned long long m = mC & __builtin_amdgcn_ballot_w64(hi > 0);   // sift.cc:72: only positive scores count
-    // ~row is the low word of the packed (score, row): the maximum takes the lower row among equal scores
-    const uint32_t nrow = ~(uint32_t)(row0 + wave * kSiftWaveRows + j * 32 + lr);
-    const unsigned long long mine = ((unsigned long long)(uint32_t)hi << 32) | nrow;
-    unsigned long long old, sv;
-    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                 "ds_max_rtn_u64 %[old], %[a], %[mine] offset:%c[o]\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [old] "=&v"(old), [sv] "=&s"(sv)
-                 : [m] "s"(m), [a] "v"(a16 + (uint32_t)lh * 16u), [mine] "v"(mine), [o] "n"(kLdsCb + OFF * 8)
-                 : "memory");
-    const unsigned long long loser = old < mine ? old : mine;   // (lanes outside m: garbage, not stored)
-    const int ls = (int)(loser >> 32);
-    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                 "ds_max_i32 %[a], %[l] offset:%c[o]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [sv] "=&s"(sv)
-                 : [m] "s"(m), [a] "v"(a16), [l] "v"(ls), [o] "n"(kLdsCs + OFF * 4)
-                 : "memory");
-  };
-  auto scan_block = [&](const v16i (&acc)[2], v4i (&tq)[2], const int seq, const uint32_t a16, auto blk_tag) {
-    constexpr int BLK = decltype(blk_tag)::value;
+  auto scan_block = [&](const v16i (&acc)[2], const int seq) {
     if (PCD_SIFT_ABLATE & 1) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); return; }
     const int base = __builtin_amdgcn_readfirstlane(seq * 16);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      if (COLS && g == 1) {   // thresholds of registers 8 .. 15
-        asm volatile("ds_read_b128 %0, %2 offset:%c3\n\tds_read_b128 %1, %2 offset:%c4\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(tq[0]), "=&v"(tq[1])
-                     : "v"(a16), "n"(kLdsThr + BLK * 128 + 64), "n"(kLdsThr + BLK * 128 + 96)
-                     : "memory");
-      }
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        unsigned long long mk[8], mc[8];
+      for (int g = 0; g < 2; ++g) {
+        unsigned long long mk[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          if (PCD_SIFT_ABLATE & 64) { asm volatile("s_mov_b64 %0, 0" : "=s"(mk[k])); mc[k] = 0; continue; }   // no compares
-          mk[k] = __builtin_amdgcn_ballot_w64(acc[j][8 * g + k] > m2[j]);
-          if (COLS && !(PCD_SIFT_ABLATE & 256)) {
-            mc[k] = __builtin_amdgcn_ballot_w64(acc[j][8 * g + k] > tq[k >> 2][k & 3]);   // colthr holds threshold - 1
-          } else {
-            mc[k] = 0;
-          }
+          if (PCD_SIFT_ABLATE & 64) { asm volatile("s_mov_b64 %0, 0" : "=s"(mk[k])); continue; }   // no compares
+          mk[k] = __builtin_amdgcn_ballot_w64(acc[j][8 * g + k] > thr[j]);
         }
         if (PCD_SIFT_ABLATE & 32) {   // compares only
 #pragma unroll
-          for (int k = 0; k < 8; ++k) asm volatile("" ::"s"(mk[k]), "s"(mc[k]));
+          for (int k = 0; k < 8; ++k) asm volatile("" ::"s"(mk[k]));
           continue;
         }
         // one scalar test per PAIR of registers (asm goto, which would save the s_cmp behind the s_or, is miscompiled by
@@ -339,117 +277,84 @@ __device__ __forceinline__ void sift_rows(const uint8_t* __restrict__ xr, const 
         // (a taken branch costs an instruction refetch)
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
-          const unsigned long long any = COLS ? (mk[k] | mk[k + 1]) | (mc[k] | mc[k + 1]) : (mk[k] | mk[k + 1]);
-          if (!(PCD_SIFT_ABLATE & 2) && __builtin_expect(any != 0, 0)) {
+          if (!(PCD_SIFT_ABLATE & 2) && __builtin_expect((mk[k] | mk[k + 1]) != 0, 0)) {
             if (mk[k]) slow(acc[j][8 * g + k], j, base + 8 * g + k);
             if (mk[k + 1]) slow(acc[j][8 * g + k + 1], j, base + 8 * g + k + 1);
-            if (COLS) {
-              // column of register r (lane half 0) inside the tile: 32 BLK + (r & 3) + 8 (r >> 2)
-              const int r0 = 8 * g + k, r1 = r0 + 1;
-              if (mc[k] && !(PCD_SIFT_ABLATE & 512)) col_slow(acc[j][r0], j, mc[k], a16, 32 * BLK + (r0 & 3) + 8 * (r0 >> 2));
-              if (mc[k + 1] && !(PCD_SIFT_ABLATE & 512)) col_slow(acc[j][r1], j, mc[k + 1], a16, 32 * BLK + (r1 & 3) + 8 * (r1 >> 2));
-            }
           }
         }
       }
+  };
+  // once per tile: the other lane half's second best (v_permlane32_swap: lanes 32 .. 63 of one copy <-> lanes 0 .. 31 of
+  // the other)
+  auto share_thr = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)m2[j], (unsigned)m2[j], false, false);
+      const int other = lh ? (int)sw[0] : (int)sw[1];
+      thr[j] = max(thr[j], other - 1);
     }
   };
+
   v16i acc0[2];
-  // fragments of one column block: 4 k-chunks of the staged descriptors + the 16 column constants (+ the 16 column
-  // thresholds)  (inline-asm LDS reads: for an ordinary LDS load hipcc would first drain the DMAs in flight with vmcnt(0))
-  v4i tq[2];
-  auto read_frag = [&](SiftFrag& f, const uint32_t (&fadr)[4], const uint32_t a16, auto blk_tag) {
+  // fragments of one column block: 4 k-chunks of the staged descriptors + the 16 column constants
+  // (inline-asm LDS reads: for an ordinary LDS load hipcc would first drain the DMAs in flight with vmcnt(0))
+  auto read_frag = [&](SiftFrag& f, const uint32_t fb_a, const uint32_t cc_a, auto blk_tag) {
     if (PCD_SIFT_ABLATE & 128) {   // fragments read once; opaque "new values" so that the MFMAs stay in the loop
       asm volatile("" : "+v"(f.fb[0]), "+v"(f.fb[1]), "+v"(f.fb[2]), "+v"(f.fb[3]), "+v"(f.cq[0]), "+v"(f.cq[1]), "+v"(f.cq[2]), "+v"(f.cq[3]));
       return;
     }
-    constexpr int BLK = decltype(blk_tag)::value;
-    sift_read_frag<BLK>(f, fadr[0], fadr[1], fadr[2], fadr[3], a16);
-    if (COLS)   // thresholds of registers 0 .. 7 (8 .. 15 follow inside scan_block: eight registers less across the block)
-      asm volatile("ds_read_b128 %0, %2 offset:%c3\n\tds_read_b128 %1, %2 offset:%c4"
-                   : "=&v"(tq[0]), "=&v"(tq[1])
-                   : "v"(a16), "n"(kLdsThr + BLK * 128), "n"(kLdsThr + BLK * 128 + 32)
-                   : "memory");
+    sift_read_frag<decltype(blk_tag)::value>(f, fb_a + foff[0], fb_a + foff[1], fb_a + foff[2], fb_a + foff[3], cc_a);
     // the reads have landed (the asm ties the wait to the registers: nothing that uses them moves above it)
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(f.fb[0]), "+v"(f.fb[1]), "+v"(f.fb[2]), "+v"(f.fb[3]), "+v"(f.cq[0]), "+v"(f.cq[1]), "+v"(f.cq[2]), "+v"(f.cq[3])
                  :: "memory");
-    if (COLS) asm volatile("" : "+v"(tq[0]), "+v"(tq[1]));
   };
   auto mfma_block = [&](v16i (&acc)[2], const SiftFrag& f) {
-    // register 4 q + i of the result = column 8 q + 4 lh + i of the block.  The accumulators start from
-    // column constant + row constant (32 full-rate adds per block): the results are TRUE scores, which both tests use
-    // as they are.
+    // register 4 q + i of the result = column 8 q + 4 lh + i of the block
+    v16i cc;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[j][4 * q] = f.cq[q][0] + rowc[j]; acc[j][4 * q + 1] = f.cq[q][1] + rowc[j];
-        acc[j][4 * q + 2] = f.cq[q][2] + rowc[j]; acc[j][4 * q + 3] = f.cq[q][3] + rowc[j];
-      }
+    for (int q = 0; q < 4; ++q) { cc[4 * q] = f.cq[q][0]; cc[4 * q + 1] = f.cq[q][1]; cc[4 * q + 2] = f.cq[q][2]; cc[4 * q + 3] = f.cq[q][3]; }
     if (PCD_SIFT_ABLATE & 16) return;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.fb[kk], fa[j][kk], acc[j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j)
+        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.fb[kk], fa[j][kk], kk == 0 ? cc : acc[j], 0, 0, 0);
   };
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   SiftFrag f;
-  if (PCD_SIFT_ABLATE & 128) sift_read_frag<0>(f, frag_addr(0, 0), frag_addr(0, 1), frag_addr(0, 2), frag_addr(0, 3), sL_base + (uint32_t)lh * 16u);
+  if (PCD_SIFT_ABLATE & 128) sift_read_frag<0>(f, sB_base + foff[0], sB_base + foff[1], sB_base + foff[2], sB_base + foff[3], sCc_base);
   for (int bx = bx0; bx < bx1; ++bx) {
     const int t = bx - bx0, buf = t & 1;
     if (bx + 1 < bx1) issue(bx + 1, buf ^ 1);   // the buffer's last readers passed the barrier below
     if (active) {
-      const uint32_t fadr[4] = {frag_addr(buf, 0), frag_addr(buf, 1), frag_addr(buf, 2), frag_addr(buf, 3)};
-      const uint32_t a16 = sL_base + (uint32_t)buf * (uint32_t)sizeof(SiftLdsBuf) + (uint32_t)lh * 16u;
-      read_frag(f, fadr, a16, std::integral_constant<int, 0>{});
+      share_thr();
+      const uint32_t fb_a = sB_base + (uint32_t)buf * (kSiftTile * 128);
+      const uint32_t cc_a = sCc_base + (uint32_t)buf * (kSiftTile * 4);
+      read_frag(f, fb_a, cc_a, std::integral_constant<int, 0>{});
       mfma_block(acc0, f);
-      scan_block(acc0, tq, 4 * t, a16, std::integral_constant<int, 0>{});
-      read_frag(f, fadr, a16, std::integral_constant<int, 1>{});
+      scan_block(acc0, 4 * t);
+      read_frag(f, fb_a, cc_a, std::integral_constant<int, 1>{});
       mfma_block(acc0, f);
-      scan_block(acc0, tq, 4 * t + 1, a16, std::integral_constant<int, 1>{});
-      read_frag(f, fadr, a16, std::integral_constant<int, 2>{});
+      scan_block(acc0, 4 * t + 1);
+      read_frag(f, fb_a, cc_a, std::integral_constant<int, 2>{});
       mfma_block(acc0, f);
-      scan_block(acc0, tq, 4 * t + 2, a16, std::integral_constant<int, 2>{});
-      read_frag(f, fadr, a16, std::integral_constant<int, 3>{});
+      scan_block(acc0, 4 * t + 2);
+      read_frag(f, fb_a, cc_a, std::integral_constant<int, 3>{});
       mfma_block(acc0, f);
-      scan_block(acc0, tq, 4 * t + 3, a16, std::integral_constant<int, 3>{});
+      scan_block(acc0, 4 * t + 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's part of the next tile has landed
     if (!(PCD_SIFT_ABLATE & 8)) __syncthreads();
-    if (COLS && tid < kSiftTile) {
-      // the stripe's result for the tile's columns (every wavefront is past the tile); the slots are next used two
-      // tiles on, behind the next barrier
-      const unsigned long long b = sL[buf].cb[tid];
-      const int sc = sL[buf].cs[tid];
-      const int col = bx * kSiftTile + tid;
-      if (col < n2) cpart[(size_t)by * n2 + col] = make_int4((int)(b >> 32), sc, (b >> 32) ? (int)~(uint32_t)b : -1, 0);
-      sL[buf].cb[tid] = 0ull;
-      sL[buf].cs[tid] = 0;
-    }
-  }
-  if (!COLS && !part) {
-    // the seed launch: the rows' true second best; the image's padding rows (up to a multiple of 128) can never be reached
-    const int npad = (n1 + kSiftTile - 1) / kSiftTile * kSiftTile;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int best = m1[nt];
-      int second = m2[nt];
-      second = max(max(second, __shfl_xor(second, 32)), min(best, __shfl_xor(best, 32)));   // second best of both halves
-      const int grow = row0 + wave * kSiftWaveRows + nt * 32 + lr;
-      // (threshold - 1: the column test is "score > colthr", a score EQUAL to the sample's second best must pass)
-      if (lh == 0 && grow < npad) seed_out[grow] = (active && grow < n1) ? second - 1 : 0x7fffffff;
-    }
-    return;
   }
   if (!active) return;
 
   // ---- end of the walk: decode, merge the two lane halves of a row, write the chunk's partial
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
-    int best = m1[nt], second = m2[nt], a = -1;
+    int best = m1[nt] + rowc[nt], second = m2[nt] + rowc[nt], a = -1;
     if (arg[nt] >= 0) {
       const int seq = arg[nt] >> 4, reg = arg[nt] & 15;
       a = (bx0 + (seq >> 2)) * kSiftTile + (seq & 3) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
@@ -461,62 +366,44 @@ __device__ __forceinline__ void sift_rows(const uint8_t* __restrict__ xr, const 
   }
 }
 
-// Seed launch: for every descriptor of set 2 its second-best score over the first kSiftSeedTiles tiles of set 1 -- the
-// thresholds of the column side of the main launch (thr: one int per row of the prepared copy of set 2).
-constexpr int kSiftSeedTiles = 8;
-
-__global__ __launch_bounds__(64 * kSiftWaves, PCD_SIFT_WGS) void k_sift_seed_stripe(const uint8_t* __restrict__ xa,
-                                                          const int* __restrict__ cc, uint32_t prow1, int n1,
-                                                          uint32_t prow2, int n2, int* __restrict__ thr) {
-  if ((int)blockIdx.y * kSiftStripe >= (n2 + kSiftTile - 1) / kSiftTile * kSiftTile) return;
-  const int nb = min((n1 + kSiftTile - 1) / kSiftTile, kSiftSeedTiles);
-  sift_rows<false>(xa + (size_t)prow2 * 128, cc + prow2, n2, xa + (size_t)prow1 * 128, cc + prow1, nb, nullptr, nb, 0,
-                   blockIdx.y, thr, nullptr, nullptr, 0);
-}
-
-// Main launch: workgroup (chunk, stripe) of the ONE product rows of set 1 x columns of set 2.
-// part12 [chunks][n1]: the rows' partials; part21 [stripes of set 1][n2]: the columns' partials.
+// blockIdx.z = direction: 0 = rows of set 1 over the columns of set 2 (part12), 1 = the sets exchanged (part21).
+// ct12 / ct21: column tiles per chunk of the two directions; workgroups past a direction's stripes or chunks leave.
 __global__ __launch_bounds__(64 * kSiftWaves, PCD_SIFT_WGS) void k_sift_scores_stripe(const uint8_t* __restrict__ xa,
                                                             const int* __restrict__ cc, uint32_t prow1, int n1,
-                                                            uint32_t prow2, int n2, const int* __restrict__ thr,
-                                                            int4* __restrict__ part12, int4* __restrict__ part21,
-                                                            int ct12) {
-  sift_rows<true>(xa + (size_t)prow1 * 128, cc + prow1, n1, xa + (size_t)prow2 * 128, cc + prow2,
-                  (n2 + kSiftTile - 1) / kSiftTile, part12, ct12, blockIdx.x, blockIdx.y, nullptr, thr, part21, n2);
+                                                            uint32_t prow2, int n2, int4* __restrict__ part12,
+                                                            int4* __restrict__ part21, int ct12, int ct21) {
+  // (one call site: the walk is ~20 KB of code)
+  const bool fwd = blockIdx.z == 0;
+  const uint32_t pr = fwd ? prow1 : prow2, pc = fwd ? prow2 : prow1;
+  const int nr = fwd ? n1 : n2, nc = fwd ? n2 : n1;
+  if ((int)blockIdx.y * kSiftStripe >= nr) return;
+  sift_rows(xa + (size_t)pr * 128, cc + pr, nr, xa + (size_t)pc * 128, cc + pc, (nc + kSiftTile - 1) / kSiftTile,
+            fwd ? part12 : part21, fwd ? ct12 : ct21, blockIdx.x, blockIdx.y);
 }
 
 // ---- many image pairs in one launch set (pcd_sift_match_batch_device) ----------------------------------
-// All descriptors live in one arena; a pair names two row ranges of it.  blockIdx.z = pair; the grid's x / y extents
-// are sized for the largest set of the batch, smaller ones leave early.
+// All descriptors live in one arena; a pair names two row ranges of it.  blockIdx.z = 2 pair + direction; the grid's
+// x / y extents are sized for the largest set of the batch, smaller ones leave early.
 struct SiftPairDev {
   uint32_t prow1, n1, prow2, n2; // rows of the two images in the prepared copy, their sizes
   uint64_t part12, part21;       // int4 offsets of the pair's partial results
   uint64_t m12, m21;             // int offsets of the pair's best-match arrays
   uint64_t match;                // offset (in matches) of the pair's output list
-  uint64_t thr;                  // int offset of the pair's column thresholds (n2 padded to 128)
 };
-
-__global__ __launch_bounds__(64 * kSiftWaves, PCD_SIFT_WGS) void k_sift_seed_batch(const uint8_t* __restrict__ xa,
-                                                         const int* __restrict__ cc,
-                                                         const SiftPairDev* __restrict__ pairs, int* __restrict__ thr) {
-  const SiftPairDev pr = pairs[blockIdx.z];
-  if (pr.n1 == 0 || (int)blockIdx.y * kSiftStripe >= ((int)pr.n2 + kSiftTile - 1) / kSiftTile * kSiftTile) return;
-  const int nb = min(((int)pr.n1 + kSiftTile - 1) / kSiftTile, kSiftSeedTiles);
-  sift_rows<false>(xa + (size_t)pr.prow2 * 128, cc + pr.prow2, (int)pr.n2, xa + (size_t)pr.prow1 * 128, cc + pr.prow1, nb,
-                   nullptr, nb, 0, blockIdx.y, thr + pr.thr, nullptr, nullptr, 0);
-}
 
 __global__ __launch_bounds__(64 * kSiftWaves, PCD_SIFT_WGS) void k_sift_scores_batch(const uint8_t* __restrict__ xa,
                                                            const int* __restrict__ cc,
                                                            const SiftPairDev* __restrict__ pairs,
-                                                           const int* __restrict__ thr, int4* __restrict__ part12,
-                                                           int4* __restrict__ part21, int nchunk) {
-  const SiftPairDev pr = pairs[blockIdx.z];
-  if ((int)blockIdx.y * kSiftStripe >= (int)pr.n1) return;
-  const int nb = ((int)pr.n2 + kSiftTile - 1) / kSiftTile;   // chunks past the last column tile leave inside sift_rows
-  sift_rows<true>(xa + (size_t)pr.prow1 * 128, cc + pr.prow1, (int)pr.n1, xa + (size_t)pr.prow2 * 128, cc + pr.prow2, nb,
-                  part12 + pr.part12, (nb + nchunk - 1) / nchunk, blockIdx.x, blockIdx.y, nullptr, thr + pr.thr,
-                  part21 + pr.part21, (int)pr.n2);
+                                                           int4* __restrict__ part12, int4* __restrict__ part21,
+                                                           int nchunk) {
+  const SiftPairDev pr = pairs[blockIdx.z >> 1];
+  const bool fwd = (blockIdx.z & 1) == 0;
+  const uint32_t rr = fwd ? pr.prow1 : pr.prow2, rc = fwd ? pr.prow2 : pr.prow1;
+  const int nr = (int)(fwd ? pr.n1 : pr.n2), nc = (int)(fwd ? pr.n2 : pr.n1);
+  if ((int)blockIdx.y * kSiftStripe >= nr) return;
+  const int nb = (nc + kSiftTile - 1) / kSiftTile;   // chunks past the last column tile leave inside sift_rows
+  sift_rows(xa + (size_t)rr * 128, cc + rr, nr, xa + (size_t)rc * 128, cc + rc, nb,
+            fwd ? part12 + pr.part12 : part21 + pr.part21, (nb + nchunk - 1) / nchunk, blockIdx.x, blockIdx.y);
 }
 
 // sift.cc:72-104: merge the per-tile triples in ascending tile order, then the distance / ratio tests.
@@ -576,9 +463,8 @@ __global__ __launch_bounds__(256) void k_sift_finalize_batch(const SiftPairDev* 
                                                              int* __restrict__ m21) {
   const SiftPairDev pr = pairs[blockIdx.z];
   const int nb1 = ((int)pr.n1 + kSiftTile - 1) / kSiftTile, nb2 = ((int)pr.n2 + kSiftTile - 1) / kSiftTile;
-  (void)nb1;
   sift_finalize(part12 + pr.part12, (int)pr.n1, sift_chunks_used(nb2, nchunk), part21 + pr.part21, (int)pr.n2,
-                ((int)pr.n1 + kSiftStripe - 1) / kSiftStripe, max_ratio, max_distance, m12 + pr.m12, m21 + pr.m21);
+                sift_chunks_used(nb1, nchunk), max_ratio, max_distance, m12 + pr.m12, m21 + pr.m21);
 }
 
 // sift.cc:118-143 for n1 <= 1024 * kCompactPer: cross check, ordered compaction and count in ONE workgroup
@@ -679,7 +565,6 @@ struct SiftScratch {
   DevBuf<uint8_t> d1, d2;
   DevBuf<uint8_t> xa;   // the prepared copy (k_sift_prep_*): re-centred bytes, images padded to 128 rows, + one stripe of slack
   DevBuf<int> cc;       // its per-row constants
-  DevBuf<int> thr;      // column thresholds of the main launch (seed launch), per pair
   DevBuf<SiftImageDev> images;
   PinnedBuf<SiftImageDev> h_images;
   DevBuf<int> m12, m21, count;
@@ -735,19 +620,18 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
   // pcd_sift_set_tuning (tests / fuzzing) can force the number of column chunks, e.g. 1 = every stripe walks all tiles
   const int nchunk_set = g_sift_nchunk.load(std::memory_order_relaxed);
   auto chunks = [&](int nrow_tiles, int ncol_tiles) {
-    const int stripes = (n1 + kSiftStripe - 1) / kSiftStripe;
+    const int stripes = (n1 + kSiftStripe - 1) / kSiftStripe + (n2 + kSiftStripe - 1) / kSiftStripe;
     const int want = nchunk_set > 0 ? std::min(nchunk_set, ncol_tiles) : std::min(ncol_tiles, (512 + stripes - 1) / stripes);
     (void)nrow_tiles;
     return std::max(1, want);
   };
-  const int nchunk12 = chunks(nb1, nb2);
-  const int ct12 = (nb2 + nchunk12 - 1) / nchunk12;
-  const int used12 = sift_chunks_used(nb2, nchunk12);
-  const int ns1 = (n1 + kSiftStripe - 1) / kSiftStripe;
+  const int nchunk12 = chunks(nb1, nb2), nchunk21 = chunks(nb2, nb1);
+  const int ct12 = (nb2 + nchunk12 - 1) / nchunk12, ct21 = (nb1 + nchunk21 - 1) / nchunk21;
+  const int used12 = sift_chunks_used(nb2, nchunk12), used21 = sift_chunks_used(nb1, nchunk21);
   const uint32_t prow1 = 0, prow2 = (uint32_t)nb1 * kSiftTile;
   const size_t prows = (size_t)(nb1 + nb2) * kSiftTile + kSiftStripe;   // a stripe's row fragments are read unconditionally
-  PCD_TRY(sc.xa.reserve(prows * 128)); PCD_TRY(sc.cc.reserve(prows)); PCD_TRY(sc.thr.reserve((size_t)nb2 * kSiftTile));
-  PCD_TRY(sc.part12.reserve((size_t)n1 * used12)); PCD_TRY(sc.part21.reserve((size_t)n2 * ns1));
+  PCD_TRY(sc.xa.reserve(prows * 128)); PCD_TRY(sc.cc.reserve(prows));
+  PCD_TRY(sc.part12.reserve((size_t)n1 * used12)); PCD_TRY(sc.part21.reserve((size_t)n2 * used21));
   PCD_TRY(sc.keep.reserve(n1)); PCD_TRY(sc.pos.reserve(n1));
   {
     ScopedKernelTimer t("sift_prep", s);
@@ -755,19 +639,15 @@ static pcd_status sift_device(int device, const uint8_t* d_d1, int n1, const uin
                        SiftImageDev{d_d2, (uint32_t)n2, prow2}, sc.xa.p, sc.cc.p);
   }
   {
-    ScopedKernelTimer t("sift_seed", s);
-    hipLaunchKernelGGL(k_sift_seed_stripe, dim3(1, (nb2 * kSiftTile + kSiftStripe - 1) / kSiftStripe), dim3(64 * kSiftWaves), 0, s,
-                       sc.xa.p, sc.cc.p, prow1, n1, prow2, n2, sc.thr.p);
-  }
-  {
     ScopedKernelTimer t("sift_scores", s);
-    hipLaunchKernelGGL(k_sift_scores_stripe, dim3(used12, ns1), dim3(64 * kSiftWaves), 0, s, sc.xa.p, sc.cc.p, prow1, n1,
-                       prow2, n2, sc.thr.p, sc.part12.p, sc.part21.p, ct12);
+    const int ns1 = (n1 + kSiftStripe - 1) / kSiftStripe, ns2 = (n2 + kSiftStripe - 1) / kSiftStripe;
+    hipLaunchKernelGGL(k_sift_scores_stripe, dim3(std::max(used12, used21), std::max(ns1, ns2), 2), dim3(64 * kSiftWaves), 0, s, sc.xa.p,
+                       sc.cc.p, prow1, n1, prow2, n2, sc.part12.p, sc.part21.p, ct12, ct21);
   }
   {
     ScopedKernelTimer t("sift_finalize", s);
     hipLaunchKernelGGL(k_sift_finalize, dim3(div_up(((uint64_t)n1 + n2) * 16, 256)), dim3(256), 0, s, sc.part12.p, n1,
-                       used12, sc.part21.p, n2, ns1, max_ratio, max_distance, d_m12, d_m21);
+                       used12, sc.part21.p, n2, used21, max_ratio, max_distance, d_m12, d_m21);
   }
   {
     ScopedKernelTimer t("sift_compact", s);
@@ -841,7 +721,7 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
   std::vector<int> cut;   // sub-batch boundaries
   std::vector<int> cut_nchunk;
   cut.push_back(0);
-  size_t max12 = 0, max21 = 0, maxm12 = 0, maxm21 = 0, maxthr = 0;
+  size_t max12 = 0, max21 = 0, maxm12 = 0, maxm21 = 0;
   {
     int p0 = 0;
     while (p0 < n_pairs) {
@@ -850,26 +730,25 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
       const uint32_t a0 = pair_ids[2 * p0], b0 = pair_ids[2 * p0 + 1];
       const int nby0 = std::max<int>(1, (int)((first_row[a0 + 1] - first_row[a0] + kSiftTile - 1) / kSiftTile));
       const int nbx0 = std::max<int>(1, (int)((first_row[b0 + 1] - first_row[b0] + kSiftTile - 1) / kSiftTile));
-      const long stripes0 = (nby0 * kSiftTile + kSiftStripe - 1) / kSiftStripe;   // row stripes of a pair
+      const long stripes0 = (nby0 * kSiftTile + kSiftStripe - 1) / kSiftStripe + (nbx0 * kSiftTile + kSiftStripe - 1) / kSiftStripe;   // stripes of both directions
       const long left = n_pairs - p0;
       const int nchunk_env = g_sift_nchunk.load(std::memory_order_relaxed);
-      const long want = nchunk_env > 0 ? std::min<long>(nchunk_env, nbx0)
-                                       : std::min<long>(nbx0, (512 + stripes0 * left - 1) / (stripes0 * left));
+      const long want = nchunk_env > 0 ? std::min<long>(nchunk_env, std::max(nbx0, nby0))
+                                       : std::min<long>(std::max(nbx0, nby0), (512 + stripes0 * left - 1) / (stripes0 * left));
       const int nchunk = (int)std::max<long>(1, want);
-      size_t o12 = 0, o21 = 0, om12 = 0, om21 = 0, othr = 0;
+      size_t o12 = 0, o21 = 0, om12 = 0, om21 = 0;
       int p = p0;
       for (; p < n_pairs; ++p) {
         const uint32_t a = pair_ids[2 * p], b = pair_ids[2 * p + 1];
         uint64_t n1 = first_row[a + 1] - first_row[a], n2 = first_row[b + 1] - first_row[b];
         if (n1 == 0 || n2 == 0) n1 = n2 = 0;   // an empty image: no matches (sift_test.cc:311-318); every kernel skips the pair
-        // rows: one partial per column chunk; columns: one per 512-row stripe of the pair
-        const size_t need12 = (size_t)nchunk * n1, need21 = (size_t)((n1 + kSiftStripe - 1) / kSiftStripe) * n2;
-        // (the budget counts 16-byte units: both partial arrays are int4)
-        if (p > p0 && (o12 + need12 + o21 + need21 > budget || p - p0 >= 65535)) break;
-        tab[p] = SiftPairDev{imgs[a].prow, (uint32_t)n1, imgs[b].prow, (uint32_t)n2, o12, o21, om12, om21, match_offset[p], othr};
-        o12 += need12; o21 += need21; om12 += n1; om21 += n2; othr += (n2 + kSiftTile - 1) / kSiftTile * kSiftTile;
+        const size_t need12 = (size_t)nchunk * n1, need21 = (size_t)nchunk * n2;
+        // (the budget counts 16-byte units: both partial arrays are int4; 2 z-slices per pair in the scores launch)
+        if (p > p0 && (o12 + need12 + o21 + need21 > budget || p - p0 >= 32767)) break;
+        tab[p] = SiftPairDev{imgs[a].prow, (uint32_t)n1, imgs[b].prow, (uint32_t)n2, o12, o21, om12, om21, match_offset[p]};
+        o12 += need12; o21 += need21; om12 += n1; om21 += n2;
       }
-      max12 = std::max(max12, o12); max21 = std::max(max21, o21); maxthr = std::max(maxthr, othr);
+      max12 = std::max(max12, o12); max21 = std::max(max21, o21);
       maxm12 = std::max(maxm12, om12); maxm21 = std::max(maxm21, om21);
       cut.push_back(p);
       cut_nchunk.push_back(nchunk);
@@ -877,7 +756,7 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
     }
   }
   PCD_TRY(sc.pairs.reserve(n_pairs));
-  PCD_TRY(sc.part12.reserve(max12)); PCD_TRY(sc.part21.reserve(max21)); PCD_TRY(sc.thr.reserve(maxthr));
+  PCD_TRY(sc.part12.reserve(max12)); PCD_TRY(sc.part21.reserve(max21));
   PCD_TRY(sc.m12.reserve(maxm12)); PCD_TRY(sc.m21.reserve(maxm21));
   // the table goes up ON THE CALLER'S STREAM (a null-stream copy is not ordered against a non-blocking stream: a second
   // call could overwrite sc.pairs under the first call's kernels); pinned staging, guarded by ev_tab
@@ -901,14 +780,9 @@ static pcd_status sift_batch_device(int device, const uint8_t* d_arena, const ui
     }
     if (mx1 && mx2) {
       {
-        ScopedKernelTimer t("sift_seed", s);
-        hipLaunchKernelGGL(k_sift_seed_batch, dim3(1, (mx2 + kSiftTile - 1) / kSiftTile * kSiftTile / kSiftStripe + 1, np),
-                           dim3(64 * kSiftWaves), 0, s, sc.xa.p, sc.cc.p, sc.pairs.p + p0, sc.thr.p);
-      }
-      {
         ScopedKernelTimer t("sift_scores", s);
-        hipLaunchKernelGGL(k_sift_scores_batch, dim3(nchunk, (mx1 + kSiftStripe - 1) / kSiftStripe, np), dim3(64 * kSiftWaves), 0, s,
-                           sc.xa.p, sc.cc.p, sc.pairs.p + p0, sc.thr.p, sc.part12.p, sc.part21.p, nchunk);
+        hipLaunchKernelGGL(k_sift_scores_batch, dim3(nchunk, (std::max(mx1, mx2) + kSiftStripe - 1) / kSiftStripe, 2 * np),
+                           dim3(64 * kSiftWaves), 0, s, sc.xa.p, sc.cc.p, sc.pairs.p + p0, sc.part12.p, sc.part21.p, nchunk);
       }
       {
         ScopedKernelTimer t("sift_finalize", s);
