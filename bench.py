@@ -496,6 +496,8 @@ def main():
         extras["sift_block"] = dict(workload=f"{n_img} images x {n_desc} descriptors, {len(pairs)} pairs (one exhaustive-matcher block)",
                                     ms=t_sift * 1e3, us_per_pair=t_sift / len(pairs) * 1e6, pairs_per_sec=len(pairs) / t_sift,
                                     useful_TOPs=useful, useful_frac_of_dense_i8_peak=useful / 5000.0,
+                                    executed_TOPs=2 * useful, executed_frac_of_dense_i8_peak=2 * useful / 5000.0,
+                                    executed_def="every score tile is multiplied twice, once per matching direction (csrc/sift.hip)",
                                     matches=int(d_c.sum().item()), config5_450_images_s=101025 * t_sift / len(pairs))
         del d_arena, d_m, d_c
         # config 5 itself: 450 images, all 101 025 pairs, block by block as ExhaustiveFeatureMatcher::Run
@@ -629,7 +631,11 @@ def main():
             kernels["k_sift_scores_batch"] = dict(kernel="k_sift_scores_batch (+ finalize, compaction)", bound="mfma",
                                                   achieved=sb["useful_TOPs"], peak=5000.0, unit="TOP/s",
                                                   frac=sb["useful_frac_of_dense_i8_peak"], traffic=None,
-                                                  launch_ms=sb["ms"], algorithmic_flops_def="2 x 128 x n1 x n2 per pair")
+                                                  launch_ms=sb["ms"], algorithmic_flops_def="2 x 128 x n1 x n2 per pair",
+                                                  executed_frac=sb["executed_frac_of_dense_i8_peak"],
+                                                  note="useful = one product per pair; the kernel executes two (one walk per "
+                                                       "direction) at ~2.1 GHz under the 1.26 kW socket power it draws "
+                                                       "(DESIGN.md section 4.6)")
         kernels = {k: v for k, v in kernels.items() if v}
         ba_alg = (200 + 44) * O + (100 + 76) * L
         traffic, hbm_frac = brick.get("traffic"), brick.get("hbm_frac")

@@ -39,9 +39,9 @@ pcdhip.profile_enable(False)
 for k, (n, t) in p.items():
     print("  %-16s %8.3f ms/launch" % (k, t / n))
 sc = p["sift_scores"][1] / p["sift_scores"][0]
-ops = 2.0 * 128 * n1 * n2              # one S = D1.D2^T (round 3: every tile is multiplied once)
+ops = 2.0 * 128 * n1 * n2              # useful = one S = D1.D2^T (round 4: every tile is multiplied twice, once per direction)
 print("pair %d x %d: %.3f ms -> %.0f pairs/s; %d matches" % (n1, n2, ms, 1e3 / ms, int(cnt.item())))
-print("k_sift_scores: %.3f ms, %.1f TOP/s int8 MFMA (executed = useful), dense i8 peak ~5000 TOP/s" % (sc, ops / sc / 1e9))
+print("k_sift_scores: %.3f ms, %.1f useful TOP/s int8 MFMA (executed = 2 x useful), dense i8 peak ~5000 TOP/s" % (sc, ops / sc / 1e9))
 
 # ---- a block of the exhaustive matcher through the batched entry (SiftFeatureMatcher::Match(image_pairs),
 # feature/matching.cc:798; ExhaustiveMatchingOptions::block_size = 50 images) ----
