@@ -635,7 +635,7 @@ def main():
                                                   executed_frac=sb["executed_frac_of_dense_i8_peak"],
                                                   note="useful = one product per pair; the kernel executes two (one walk per "
                                                        "direction) at ~2.1 GHz under the 1.26 kW socket power it draws "
-                                                       "(DESIGN.md section 4.6)")
+                                                       "(DESIGN.md section 4.4)")
         kernels = {k: v for k, v in kernels.items() if v}
         ba_alg = (200 + 44) * O + (100 + 76) * L
         traffic, hbm_frac = brick.get("traffic"), brick.get("hbm_frac")
