@@ -666,6 +666,9 @@ def main():
         out.update(extras)
         if cs:
             out["cloud_sharded"] = cs
+            # both N > 1 decompositions side by side (north_star names the second): NN + association queries/s
+            out["nn_modes"] = {"replicated_cloud_query_split": out.get("nn_queries_per_sec"),
+                               "cloud_sharded_min_allreduce": cs.get("queries_per_sec")}
         if not a.no_cpu_baseline and world == 1:   # reported at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(xyz, nrm, q_all, mr_all, scene, min(a.cpu_sample_queries, Qtot),
                                                min(a.cpu_sample_points, Ptot))

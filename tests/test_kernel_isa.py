@@ -88,3 +88,31 @@ def test_tile_loop_has_only_its_own_vmem_operations(nn_isa):
                 elif re.match(r"\.LBB|s_cbranch|s_branch", ln):
                     break      # left the basic block: the tile was issued in the predecessor
                 j -= 1
+
+
+@pytest.fixture(scope="module")
+def sift_isa(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "sift.s"
+    subprocess.check_call([HIPCC] + FLAGS + [os.path.join(ROOT, "colmap-pcd_amd", "csrc", "sift.hip"), "-o", str(out)])
+    return out.read_text()
+
+
+def test_sift_walk_resources_and_fast_path(sift_isa):
+    """the SIFT walk (csrc/sift.hip sift_rows): 4 wavefronts per SIMD with 8-wavefront workgroups (<= 128 VGPRs, two
+    workgroups' LDS per CU), no spills (a reload in the block loop would put a vmcnt(0) in front of the tile's LDS-DMA),
+    8 MFMAs and 8 LDS fragment reads per block, and the per-register test as compares into SGPR pairs -- not one
+    v_cmp -> s_cbranch_vccz pair per register (3x the MFMAs' time)."""
+    meta, body = _kernels(sift_isa)
+    for part in ("k_sift_scores_batch", "k_sift_scores_stripe"):
+        k = _find(meta, part)[0]
+        m = meta[k]
+        assert m["vgpr"] <= 128 and m["scratch"] == 0, (k, m)
+        assert m["lds"] <= 80 * 1024, (k, m)
+        b = body[k]
+        assert "scratch_" not in b, k
+        assert len(re.findall(r"\bv_mfma_i32_32x32x32_i8\b", b)) == 4 * 8, k          # 4 column blocks per tile
+        assert len(re.findall(r"\bds_read_b128\b", b)) == 4 * 8, k                      # 4 fragments + 4 constant reads each
+        assert len(re.findall(r"\bglobal_load_lds_dwordx4\b", b)) == 2 * 2, k           # prologue + loop, 2 per wavefront
+        cmps = len(re.findall(r"\bv_cmp_gt_i32_e64 s\[", b)) + len(re.findall(r"\bv_cmp_gt_i32_e32 vcc", b))
+        assert cmps >= 4 * 32, (k, cmps)                                                  # one compare per register
+        assert len(re.findall(r"\bs_cbranch_vccz\b", b)) <= 8, k                         # (not one per register)
