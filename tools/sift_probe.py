@@ -79,3 +79,26 @@ for n_img, n_desc in ((50, n1),) if ONLY else ((16, n1), (50, n1), (50, 2048)):
         e1.record()
         torch.cuda.synchronize()
         print("       pair by pair: %.3f ms/pair" % (e0.elapsed_time(e1) / P))
+
+# ---- the same block on a LOW-MATCH set: every image has its own random descriptors (no image shares a descriptor pool
+# with another one), so almost nothing passes the distance / ratio tests -- the walk's tests see the same exchangeable
+# score statistics, and the time should not depend on how many matches there are
+n_img, n_desc = 50, n1
+arena = np.concatenate([np.clip(np.round(512 * (lambda g: g / np.linalg.norm(g, axis=1, keepdims=True))(
+    rng.random((n_desc, 128), dtype=np.float32) ** 2)), 0, 255).astype(np.uint8) for _ in range(n_img)], axis=0)
+first = np.arange(n_img + 1, dtype=np.uint64) * np.uint64(n_desc)
+pairs = np.array([(a, b) for a in range(n_img) for b in range(a + 1, n_img)], np.uint32)
+P = len(pairs)
+off = np.arange(P, dtype=np.uint64) * np.uint64(n_desc)
+d_arena = torch.from_numpy(arena).cuda()
+d_m = torch.empty(P * n_desc, 2, dtype=torch.int32, device="cuda")
+d_c = torch.empty(P, dtype=torch.int32, device="cuda")
+pcdhip.sift_match_batch_device(d_arena, first, pairs, d_m, off, d_c)
+torch.cuda.synchronize()
+e0.record()
+pcdhip.sift_match_batch_device(d_arena, first, pairs, d_m, off, d_c)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+print("low-match batch: %d images x %d independent descriptors, %d pairs: %.2f ms = %.3f ms/pair, %.1f useful TOP/s, %d matches"
+      % (n_img, n_desc, P, ms, ms / P, 2.0 * 128 * n_desc * n_desc * P / ms / 1e9, int(d_c.sum().item())), flush=True)
